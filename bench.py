@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- exact k-NN queries/sec on MI355X, with roofline and CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+1 000 000 points x 128 dims f32, 10 000 queries, k = 10, synthetic uniform [0,1)
+generated in HBM (counter hash, seeds 0x5EED0001 / 0x5EED0002).  A "step" is one
+pass of the hot path over the whole query batch: filter/scan kernel, exact
+re-rank + selection, and (N > 1) the all-gather + merge of per-shard top-k.
+Inputs are resident in HBM when the timed region starts.  With N > 1 the corpus
+is row-sharded over the ranks (total work fixed: strong scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- dominant kernel: algorithmic flops (2*N*D per query, SURVEY.md
+                  8d) / its average hipEvent duration, against the f32 MFMA peak;
+  cpu_baseline -- the CPU oracle's faithful ball tree ("port": the reference is
+                  Rust and cannot be built here) timed on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (n_points, dim, n_queries, k)
+    "c2": (1_000_000, 128, 10_000, 10),        # BASELINE.json configs[1] (headline)
+    "c3": (10_000_000, 128, 100_000, 100),     # configs[2]
+    "c4": (10_000_000, 768, 100_000, 10),      # configs[3] (8 GPUs in BASELINE; fits one here)
+    "c5": (100_000_000, 96, 1_000_000, 10),    # configs[4]
+    "tiny": (20_000, 128, 512, 10),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
+
+
+def cpu_baseline(n, dim, k, budget_queries=None):
+    """Faithful ball tree (oracle/oracle_impl.h) on this host: all-core QPS, single-thread QPS, build s."""
+    import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    n_cpu = min(n, 1_000_000)
+    pts = oracle.fill_uniform(n_cpu * dim, SEED_P).reshape(n_cpu, dim)
+    par = max(0, min(4, int(np.log2(max(cores, 1)))))
+    t0 = time.perf_counter()
+    tree = oracle.Tree(pts, build_threads_log2=par)
+    t_build = time.perf_counter() - t0
+    nq1 = 4
+    nqa = budget_queries or max(2 * cores, 16)
+    qs = oracle.fill_uniform((nq1 + nqa) * dim, SEED_Q).reshape(nq1 + nqa, dim)
+    t0 = time.perf_counter()
+    tree.query_batch(qs[:nq1], k, nthreads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tree.query_batch(qs[nq1:], k, nthreads=cores)
+    ta = time.perf_counter() - t0
+    return {
+        "value": round(nqa / ta, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+        "single_thread_qps": round(nq1 / t1, 3), "build_s": round(t_build, 2),
+        "sample": (f"C restatement of petal-neighbors' BallTree (oracle/), {n_cpu}x{dim} f32 corpus"
+                   f"{'' if n_cpu == n else ' (sub-sampled from %d rows)' % n}, k={k}: {nqa} queries on {cores} threads "
+                   f"(one query per thread), {nq1} queries on 1 thread; tree build ({2**par} threads) {t_build:.1f} s excluded"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--engine", default="auto", choices=["auto", "exact", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--segments", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device(f"cuda:{local_rank if world > 1 else 0}")
+
+    import petal_neighbors_amd as pn
+    from petal_neighbors_amd import _lib
+    from petal_neighbors_amd.sharded import ShardedBallTree, shard_bounds
+    L = _lib.lib()
+
+    n, dim, nq, k = CONFIGS[args.config]
+
+    def gen(rows_lo, rows_hi, seed):
+        t = torch.empty((rows_hi - rows_lo, dim), dtype=torch.float32, device=dev)
+        rc = L.pn_fill_uniform_device_f32(t.data_ptr(), t.numel(), seed, rows_lo * dim, dev.index, None)
+        assert rc == 0, _lib.last_error()
+        return t
+
+    queries = gen(0, nq, SEED_Q)
+    torch.cuda.synchronize()
+    index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P))
+    tree = index.engine.tree
+    tree.set_engine(args.engine)
+    if args.segments:
+        tree.set_option(_lib.PN_OPT_SEGMENTS, args.segments)
+    tree.set_option(_lib.PN_OPT_PROFILE, 1)
+    n_local = index.n_local
+    torch.cuda.synchronize()
+
+    def step():
+        return index.query_batch(queries, k)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    tree.stats(reset=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = tree.stats()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = nq * args.steps / elapsed
+        # dominant kernel: one launch covers all nq queries against this rank's shard
+        launches = max(int(st["hot_launches"]), 1)
+        hot_ms = st["hot_ms"] / launches
+        flops_per_launch = 2.0 * n_local * dim * nq  # 2*N*D per query
+        achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
+        engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
+        line = {
+            "metric": "exact k-NN queries/sec (1M x 128 fp32, k=10)" if args.config == "c2"
+                      else f"exact k-NN queries/sec ({n} x {dim} fp32, k={k})",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} points x {dim} dims f32, {nq} queries, k={k}, uniform[0,1)",
+                       "n_points": n, "dim": dim, "n_queries": nq, "k": k, "engine": engine_used,
+                       "sharding": f"corpus rows / {world}" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "mfma_filter_kernel" if engine_used == "mfma" else "exact_knn_kernel",
+                         "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
+                         "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
+                                                  / (PEAK_F32_MFMA_TFLOPS * world), 4)},
+            "fallback_queries": int(st["fallback_queries"]),
+            "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, dim, k)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+/*
+ * petal_mi355x.h -- C ABI of the MI355X-native exact k-NN engine that drops in
+ * behind petal-neighbors' BallTree::{euclidean, query, query_radius,
+ * query_nearest} and distance::{Euclidean, pairwise}.
+ *
+ * petal-neighbors (Rust, /root/reference) has no FFI of its own: its boundary
+ * is the public Rust API.  Each entry point below cites the reference item it
+ * replaces (file:line relative to the reference checkout).  INTEGRATION.md
+ * shows the Rust `extern "C"` block + safe wrapper a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions, no C++ or torch types.
+ *   - every function returns PN_OK (0) or a PN_ERR_* code; pn_last_error()
+ *     returns a thread-local message for the last failure on this thread.
+ *   - strides are in ELEMENTS, not bytes.
+ *   - "host" entry points take host pointers (what an ndarray hands over) and
+ *     do the PCIe transfers themselves; "_device" entry points take pointers
+ *     into the index's GPU memory and a hipStream_t (as void*; NULL = the
+ *     index's own stream) and enqueue work without copying inputs.
+ *   - results are written into caller-allocated buffers; the only
+ *     library-allocated result (radius CSR indices) is released with pn_free.
+ *   - all query functions are re-entrant on a shared `const pn_index*`
+ *     (BallTree queries take &self and `Euclidean: Sync`, src/distance.rs:19);
+ *     create/destroy/set_option must not race with queries on the same handle.
+ *   - there is NO CPU fallback: if no usable GPU is present every compute entry
+ *     point fails with PN_ERR_DEVICE.
+ *
+ * Result contract
+ *   - distances are bit-identical to the reference's sequential, unfused
+ *     fold + sqrt (src/distance.rs:26-35) in the index's element type.
+ *   - neighbours are ordered by (distance, index); NaN distances sort last
+ *     (ordered-float semantics used at src/ball_tree.rs:396-421).  The
+ *     reference's order inside groups of exactly equal distances is
+ *     unspecified (it depends on tree shape and heap internals); this library
+ *     returns ascending index there.
+ */
+#ifndef PETAL_MI355X_H
+#define PETAL_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_ABI_VERSION 1
+
+/* ---- error codes.  EMPTY / NOT_CONTIGUOUS are ArrayError (src/lib.rs:9-16). */
+enum {
+    PN_OK = 0,
+    PN_ERR_EMPTY = 1,          /* "array is empty"                     src/ball_tree.rs:44-46 */
+    PN_ERR_NOT_CONTIGUOUS = 2, /* "array is not contiguous in memory"  src/ball_tree.rs:47-49 */
+    PN_ERR_INVALID = 3,        /* NULL pointer / bad argument (no reference counterpart) */
+    PN_ERR_DEVICE = 4,         /* HIP failure or no GPU */
+    PN_ERR_NOMEM = 5,
+    PN_ERR_UNSUPPORTED = 6,
+    PN_ERR_EMPTY_MATRIX = 7    /* zero columns with >= 2 rows: the reference panics "empty matrix" (src/ball_tree.rs:582) */
+};
+
+/* engine selection, PN_OPT_ENGINE */
+enum {
+    PN_ENGINE_AUTO = 0,  /* MFMA filter + exact re-rank when applicable, else exact scan */
+    PN_ENGINE_EXACT = 1, /* exact VALU scan only (always bit-exact by construction) */
+    PN_ENGINE_MFMA = 2   /* force the MFMA filter path (f32 only); verified, falls back per query */
+};
+
+enum {
+    PN_OPT_ENGINE = 1,
+    PN_OPT_SEGMENTS = 2,    /* corpus row segments per query tile; 0 = auto */
+    PN_OPT_INDEX_BASE = 3,  /* added to every returned index (row-sharded corpora) */
+    PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream */
+    PN_OPT_FILTER_SLOTS = 5 /* k' kept by the MFMA filter per (query, segment); 0 = auto */
+};
+
+typedef struct pn_index pn_index;
+
+typedef struct pn_info {
+    uint64_t n_points; /* BallTree::num_points  src/ball_tree.rs:351-353 */
+    uint64_t dim;
+    uint64_t row_stride_device; /* padded row length in HBM (elements) */
+    int32_t elem_bytes;         /* 4 = f32, 8 = f64 */
+    int32_t device;
+    int32_t mfma_eligible; /* 1 when the MFMA filter path can serve this index */
+    int32_t reserved;
+} pn_info;
+
+typedef struct pn_stats {
+    uint64_t queries;          /* k-NN queries served */
+    uint64_t fallback_queries; /* queries whose MFMA-filter result failed verification and were re-run exactly */
+    uint64_t candidates;       /* candidates re-ranked exactly */
+    uint64_t hot_launches;     /* launches of the dominant kernel inside profiled calls */
+    double hot_ms;             /* their summed hipEvent duration (PN_OPT_PROFILE=1) */
+    double last_call_ms;       /* hipEvent duration of the whole last profiled *_device call */
+    uint64_t radius_results;
+    uint64_t reserved[4];
+} pn_stats;
+
+const char *pn_last_error(void);
+const char *pn_strerror(int code);
+int pn_abi_version(void);
+int pn_device_count(int *count);
+
+/* ---- construction: BallTree::new / BallTree::euclidean
+ * (src/ball_tree.rs:38-63, 367-373).  Validation is the reference's: zero
+ * rows -> PN_ERR_EMPTY; inner (column) stride != 1 with more than one column
+ * -> PN_ERR_NOT_CONTIGUOUS (only the inner stride is checked, as at :47); the
+ * row stride is free.  The host array is borrowed for the duration of the
+ * call only; the index keeps a zero-padded copy in HBM (plus row norms).
+ * The ball tree itself is not built: the walk is replaced by a batched scan. */
+int pn_index_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                        ptrdiff_t col_stride, int device, pn_index **out);
+int pn_index_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                        ptrdiff_t col_stride, int device, pn_index **out);
+/* same, from rows already resident on `device` (row-major, inner stride 1) */
+int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
+                               int device, void *stream, pn_index **out);
+void pn_index_destroy(pn_index *index);
+int pn_index_info(const pn_index *index, pn_info *out);
+int pn_index_set_option(pn_index *index, int option, int64_t value);
+int pn_index_get_stats(const pn_index *index, pn_stats *out, int reset);
+
+/* ---- k-NN: BallTree::query (src/ball_tree.rs:102-121, 203-243) for a batch of
+ * queries (the reference takes one point per call; nq = 1 is that call).
+ * q_cols is the length of each query vector: like the reference's `zip`
+ * (src/distance.rs:27-28) the distance runs over min(q_cols, dim) coordinates.
+ * Writes nq rows of kout = min(k, n_points) results, ascending by distance;
+ * k = 0 writes nothing and succeeds (src/ball_tree.rs:106-108).  Never fails on
+ * NaN coordinates (CHANGELOG.md:113-115). */
+int pn_query_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
+                 ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out);
+int pn_query_f64(const pn_index *index, const double *queries, size_t nq, size_t q_cols,
+                 ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, double *dist_out);
+int pn_query_device_f32(const pn_index *index, const float *d_queries, size_t nq, size_t q_cols,
+                        size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out,
+                        void *stream);
+int pn_query_device_f64(const pn_index *index, const double *d_queries, size_t nq, size_t q_cols,
+                        size_t q_row_stride, size_t k, uint64_t *d_idx_out, double *d_dist_out,
+                        void *stream);
+
+/* ---- 1-NN: BallTree::query_nearest (src/ball_tree.rs:80-86, 149-196). */
+int pn_query_nearest_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
+                         ptrdiff_t q_row_stride, uint64_t *idx_out, float *dist_out);
+int pn_query_nearest_f64(const pn_index *index, const double *queries, size_t nq, size_t q_cols,
+                         ptrdiff_t q_row_stride, uint64_t *idx_out, double *dist_out);
+
+/* ---- radius: BallTree::query_radius (src/ball_tree.rs:137-142, 250-294).
+ * Returns, per query, { i : distance(q, p_i) < r } (the leaf test at :277 is
+ * strict) in ascending index order (the reference's order is unspecified; its
+ * tests sort, :667, :777).  CSR output: offsets[nq + 1] is caller-allocated,
+ * *idx_out is allocated by the library (release with pn_free). */
+int pn_query_radius_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
+                        ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out);
+int pn_query_radius_f64(const pn_index *index, const double *queries, size_t nq, size_t q_cols,
+                        ptrdiff_t q_row_stride, double radius, uint64_t *offsets, uint64_t **idx_out);
+void pn_free(void *p);
+
+/* ---- distance::pairwise(x, &Euclidean) (src/distance.rs:58-74): n x n
+ * symmetric matrix, zero diagonal, n < 2 -> zeros. Host in, host out. */
+int pn_pairwise_f32(const float *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,
+                    float *out);
+int pn_pairwise_f64(const double *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,
+                    double *out);
+
+/* ---- Metric<A> for Euclidean (src/distance.rs:21-55): scalar, host-side by
+ * design (one pair per call is not GPU work); bit-exact with the batched path. */
+float pn_euclidean_f32(const float *a, const float *b, size_t len);
+double pn_euclidean_f64(const double *a, const double *b, size_t len);
+float pn_reuclidean_f32(const float *a, const float *b, size_t len);
+double pn_reuclidean_f64(const double *a, const double *b, size_t len);
+float pn_rdistance_to_distance_f32(float d);
+double pn_rdistance_to_distance_f64(double d);
+float pn_distance_to_rdistance_f32(float d);
+double pn_distance_to_rdistance_f64(double d);
+
+/* ---- row-sharded corpora: merge `n_parts` per-shard results
+ * (each nq x k_part, already carrying global indices via PN_OPT_INDEX_BASE and
+ * sorted by (distance, index)) into the global top k_out.  Device pointers;
+ * parts are laid out [part][query][k_part], as an all-gather leaves them.
+ * Slots with index UINT64_MAX are treated as absent. */
+int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
+                             size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
+                             float *d_dist_out, int device, void *stream);
+
+/* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
+ * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in
+ * HBM; bit-identical to oracle_fill_uniform_f32. */
+int pn_fill_uniform_device_f32(float *d_out, uint64_t count, uint64_t seed, uint64_t first_counter,
+                               int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETAL_MI355X_H */

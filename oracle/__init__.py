@@ -72,6 +72,8 @@ def _declare(L):
         f.argtypes = [C.POINTER(_SZ), _SZ, P, _SZ]
         f = getattr(L, f"oracle_tree_build_{sfx}"); f.restype = _VP
         f.argtypes = [P, _SZ, _SZ, _SZ, C.c_ssize_t, C.POINTER(_I)]
+        f = getattr(L, f"oracle_tree_build_mt_{sfx}"); f.restype = _VP
+        f.argtypes = [P, _SZ, _SZ, _SZ, C.c_ssize_t, _I, C.POINTER(_I)]
         f = getattr(L, f"oracle_tree_free_{sfx}"); f.restype = None; f.argtypes = [_VP]
         f = getattr(L, f"oracle_tree_num_nodes_{sfx}"); f.restype = _SZ; f.argtypes = [_VP]
         f = getattr(L, f"oracle_tree_idx_{sfx}"); f.restype = C.POINTER(_SZ); f.argtypes = [_VP]
@@ -221,7 +223,7 @@ def halve_node_indices(idx, col):
 class Tree:
     """Faithful restatement of ``BallTree<A, Euclidean>`` (src/ball_tree.rs)."""
 
-    def __init__(self, points):
+    def __init__(self, points, build_threads_log2=0):
         a = np.asarray(points)
         if a.ndim != 2:
             raise ValueError("points must be 2-D")
@@ -236,8 +238,9 @@ class Tree:
         self.points = np.ascontiguousarray(a)
         err = _I(0)
         L = lib()
-        self._h = getattr(L, f"oracle_tree_build_{self._s}")(
-            _ptr(self.points, self._ct), n, d, max(d, 1) if self.points.size else 0, 1, C.byref(err))
+        self._h = getattr(L, f"oracle_tree_build_mt_{self._s}")(
+            _ptr(self.points, self._ct), n, d, max(d, 1) if self.points.size else 0, 1,
+            int(build_threads_log2), C.byref(err))
         if not self._h:
             raise OracleArrayError(err.value)
         self.n, self.dim = n, d

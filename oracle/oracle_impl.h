@@ -138,6 +138,7 @@ typedef struct {
     size_t n_nodes;
     /* instrumentation (not in the reference) */
     uint64_t n_centroid_evals, n_point_evals;
+    int par_depth; /* 0 = build on one thread like the reference */
 } FN(tree_t);
 
 /* src/ball_tree.rs:445-461  Node::init */
@@ -207,6 +208,9 @@ void FN(oracle_halve_node_indices)(size_t *idx, size_t len, const T *col, size_t
     }
 }
 
+typedef struct { FN(tree_t) *t; size_t root, start, end; } FN(bjob_t);
+static void *FN(bjob_run)(void *p);
+
 /* src/ball_tree.rs:504-538  build_subtree */
 static void FN(build_subtree)(FN(tree_t) *t, size_t root, size_t start, size_t end)
 {
@@ -224,15 +228,40 @@ static void FN(build_subtree)(FN(tree_t) *t, size_t root, size_t start, size_t e
     size_t col = FN(oracle_max_spread_column)(t->pts, t->dim, t->ld, t->idx + start, end - start);
     FN(oracle_halve_node_indices)(t->idx + start, end - start, t->pts + col, t->ld);
     size_t mid = (start + end) / 2; /* :535 */
+    /* The two recursive calls touch disjoint node and idx ranges, so the top
+     * levels may run on separate threads without changing any result (test
+     * infrastructure speed-up only; the reference builds on one thread). */
+    if (t->par_depth > 0 && root < ((size_t)1 << t->par_depth) - 1) {
+        FN(bjob_t) job = { t, left, start, mid };
+        pthread_t th;
+        if (pthread_create(&th, NULL, FN(bjob_run), &job) == 0) {
+            FN(build_subtree)(t, left + 1, mid, end);
+            pthread_join(th, NULL);
+            return;
+        }
+    }
     FN(build_subtree)(t, left, start, mid);
     FN(build_subtree)(t, left + 1, mid, end);
+}
+static void *FN(bjob_run)(void *p)
+{
+    FN(bjob_t) *j = (FN(bjob_t) *)p;
+    FN(build_subtree)(j->t, j->root, j->start, j->end);
+    return NULL;
 }
 
 /* src/ball_tree.rs:38-63  BallTree::new.  Returns NULL with *err = 1 (Empty)
  * or 2 (NotContiguous: inner stride != 1), mirroring ArrayError (src/lib.rs:9-16).
  * dim == 0 with n >= 2 is the reference's "empty matrix" panic -> *err = 3. */
+FN(tree_t) *FN(oracle_tree_build_mt)(const T *pts, size_t n, size_t dim, size_t ld,
+                                     ptrdiff_t col_stride, int par_depth, int *err);
 FN(tree_t) *FN(oracle_tree_build)(const T *pts, size_t n, size_t dim, size_t ld,
                                   ptrdiff_t col_stride, int *err)
+{
+    return FN(oracle_tree_build_mt)(pts, n, dim, ld, col_stride, 0, err);
+}
+FN(tree_t) *FN(oracle_tree_build_mt)(const T *pts, size_t n, size_t dim, size_t ld,
+                                     ptrdiff_t col_stride, int par_depth, int *err)
 {
     *err = 0;
     if (n == 0) { *err = 1; return NULL; }                       /* :44-46 */
@@ -240,6 +269,7 @@ FN(tree_t) *FN(oracle_tree_build)(const T *pts, size_t n, size_t dim, size_t ld,
     if (dim == 0 && n >= 2) { *err = 3; return NULL; }           /* :582 panic */
     FN(tree_t) *t = (FN(tree_t) *)calloc(1, sizeof(*t));
     t->pts = pts; t->n = n; t->dim = dim; t->ld = ld;
+    t->par_depth = par_depth;
     unsigned height = 0; /* usize::BITS - leading_zeros(n) (:51) */
     for (size_t v = n; v; v >>= 1) ++height;
     t->n_nodes = ((size_t)1 << height) - 1; /* :52 */

@@ -1,0 +1,220 @@
+"""Host mirror of ``petal_neighbors::BallTree`` (reference src/ball_tree.rs:15-374).
+
+Same constructor names, argument meaning, result shapes and error behaviour as
+the Rust type, so tests read like the reference's own; the work is done by the
+HIP kernels behind the C ABI (``include/petal_mi355x.h``).  The ball tree walk
+is not reproduced: ``BallTree`` here owns a zero-padded copy of the points in
+HBM and answers queries by batched exact scans.
+
+Batch methods (``query_batch`` etc.) are extensions: the reference takes one
+point per call (src/ball_tree.rs:102); ``nq = 1`` is that call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .distance import Euclidean
+from .errors import check
+
+ENGINES = {"auto": _lib.PN_ENGINE_AUTO, "exact": _lib.PN_ENGINE_EXACT, "mfma": _lib.PN_ENGINE_MFMA}
+
+
+def _float_array(a):
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):  # `A: FloatCore` is f32 or f64 in practice
+        a = a.astype(np.float64)
+    return a
+
+
+class BallTree:
+    """``BallTree<'a, A, Euclidean>``: ``points`` / ``metric`` stay readable like the pub fields
+    at src/ball_tree.rs:20-23 (``idx`` and ``nodes`` do not exist: no tree is built)."""
+
+    def __init__(self, handle, points, metric, dtype, device):
+        self._h = C.c_void_p(handle)
+        self.points = points
+        self.metric = metric
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self._sfx = "f32" if self.dtype == np.float32 else "f64"
+        info = _lib.PnInfo()
+        check(_lib.lib().pn_index_info(self._h, C.byref(info)))
+        self._n, self._dim = int(info.n_points), int(info.dim)
+        self.mfma_eligible = bool(info.mfma_eligible)
+
+    # ------------------------------------------------------------ construction
+    @classmethod
+    def new(cls, points, metric, device: int = 0):
+        """``BallTree::new(points, metric)`` (src/ball_tree.rs:38-63).
+
+        Raises ``ArrayError.Empty`` for zero rows and ``ArrayError.NotContiguous`` when the
+        inner stride is not 1 (only the inner stride is checked, as at :47)."""
+        if not isinstance(metric, Euclidean):
+            raise NotImplementedError("only distance.Euclidean is on the MI355X path")
+        a = _float_array(points)
+        if a.ndim != 2:
+            raise ValueError("points must be a 2-D array (Ix2)")
+        n, d = a.shape
+        item = a.itemsize
+        rs, cs = (a.strides[0] // item, a.strides[1] // item)
+        if a.strides[0] % item or a.strides[1] % item or (n > 1 and rs < 0):
+            a = np.ascontiguousarray(a)  # exotic views: ndarray would accept them; copy, same values
+            rs, cs = d, 1
+        if d <= 1:
+            cs = 1
+            if d == 1 and a.strides[1] != item:
+                a = np.ascontiguousarray(a)
+                rs = d
+        L = _lib.lib()
+        h = C.c_void_p(0)
+        fn = L.pn_index_create_f32 if a.dtype == np.float32 else L.pn_index_create_f64
+        check(fn(a.ctypes.data if a.size else None, n, d, rs, cs, device, C.byref(h)))
+        return cls(h.value, a, metric, a.dtype, device)
+
+    @classmethod
+    def euclidean(cls, points, device: int = 0):
+        """``BallTree::euclidean(points)`` (src/ball_tree.rs:367-373)."""
+        return cls.new(points, Euclidean(), device)
+
+    @classmethod
+    def from_device(cls, tensor, stream=None):
+        """Build from a row-major float32 CUDA tensor already in HBM (extension)."""
+        import torch
+        if tensor.dtype != torch.float32 or tensor.dim() != 2 or not tensor.is_cuda:
+            raise ValueError("from_device takes a 2-D float32 CUDA tensor")
+        if tensor.shape[1] > 1 and tensor.stride(1) != 1:
+            from .errors import NotContiguous
+            raise NotContiguous()
+        n, d = tensor.shape
+        dev = tensor.device.index or 0
+        h = C.c_void_p(0)
+        st = stream if stream is not None else torch.cuda.current_stream(tensor.device).cuda_stream
+        check(_lib.lib().pn_index_create_device_f32(tensor.data_ptr() if n * d else None, n, d,
+                                                    tensor.stride(0) if n > 1 else max(d, 1), dev,
+                                                    C.c_void_p(st), C.byref(h)))
+        return cls(h.value, None, Euclidean(), np.float32, dev)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().pn_index_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    # ------------------------------------------------------------------ options
+    def set_engine(self, name: str):
+        check(_lib.lib().pn_index_set_option(self._h, _lib.PN_OPT_ENGINE, ENGINES[name]))
+        return self
+
+    def set_option(self, opt: int, value: int):
+        check(_lib.lib().pn_index_set_option(self._h, opt, int(value)))
+        return self
+
+    def stats(self, reset: bool = False):
+        s = _lib.PnStats()
+        check(_lib.lib().pn_index_get_stats(self._h, C.byref(s), int(reset)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+    # ---------------------------------------------------------------- accessors
+    def num_points(self) -> int:
+        """``BallTree::num_points`` (src/ball_tree.rs:351-353)."""
+        return self._n
+
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    # ------------------------------------------------------------------ queries
+    def _queries(self, q, one: bool):
+        a = np.ascontiguousarray(q, dtype=self.dtype)
+        if one:
+            if a.ndim != 1:
+                raise ValueError("point must be 1-D (Ix1)")
+            a = a.reshape(1, -1)
+        elif a.ndim != 2:
+            raise ValueError("queries must be 2-D")
+        return a
+
+    def query_batch(self, queries, k: int):
+        """k-NN for every row of ``queries``: (nq, min(k, n)) indices (uint64) and distances."""
+        a = self._queries(queries, False)
+        nq, qc = a.shape
+        kout = min(int(k), self._n)
+        idx = np.empty((nq, kout), dtype=np.uint64)
+        dist = np.empty((nq, kout), dtype=self.dtype)
+        if nq and kout:
+            fn = getattr(_lib.lib(), f"pn_query_{self._sfx}")
+            check(fn(self._h, a.ctypes.data, nq, qc, max(qc, 1), int(k), idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def query(self, point, k: int):
+        """``BallTree::query(point, k) -> (Vec<usize>, Vec<A>)`` ascending (src/ball_tree.rs:102-121);
+        ``k == 0`` returns two empty arrays (:106-108)."""
+        idx, dist = self.query_batch(self._queries(point, True), k)
+        return idx[0], dist[0]
+
+    def query_nearest(self, point):
+        """``BallTree::query_nearest(point) -> (usize, A)`` (src/ball_tree.rs:80-86)."""
+        a = self._queries(point, True)
+        idx = np.empty(1, dtype=np.uint64)
+        dist = np.empty(1, dtype=self.dtype)
+        fn = getattr(_lib.lib(), f"pn_query_nearest_{self._sfx}")
+        check(fn(self._h, a.ctypes.data, 1, a.shape[1], max(a.shape[1], 1), idx.ctypes.data, dist.ctypes.data))
+        return int(idx[0]), dist[0]
+
+    def query_radius_batch(self, queries, distance):
+        """CSR (offsets[nq+1], indices) of ``{ i : dist(q, p_i) < distance }``, ascending per query."""
+        a = self._queries(queries, False)
+        nq, qc = a.shape
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        out = C.c_void_p(0)
+        r = C.c_float(distance) if self._sfx == "f32" else C.c_double(distance)
+        fn = getattr(_lib.lib(), f"pn_query_radius_{self._sfx}")
+        check(fn(self._h, a.ctypes.data, nq, qc, max(qc, 1), r, offsets.ctypes.data, C.byref(out)))
+        total = int(offsets[-1])
+        try:
+            if total:
+                buf = (C.c_uint64 * total).from_address(out.value)
+                idx = np.frombuffer(buf, dtype=np.uint64).copy()
+            else:
+                idx = np.empty(0, dtype=np.uint64)
+        finally:
+            if out.value:
+                _lib.lib().pn_free(out)
+        return offsets, idx
+
+    def query_radius(self, point, distance):
+        """``BallTree::query_radius(point, distance) -> Vec<usize>`` (src/ball_tree.rs:137-142).
+        The reference's order is unspecified (its tests sort, :667/:777); here: ascending."""
+        _, idx = self.query_radius_batch(self._queries(point, True), distance)
+        return idx
+
+    # --------------------------------------------------------- device-resident
+    def query_device(self, queries, k: int, out_idx=None, out_dist=None, stream=None):
+        """k-NN with queries and results in HBM (torch CUDA tensors, float32 indices as int64)."""
+        import torch
+        if self._sfx != "f32":
+            raise NotImplementedError("query_device is float32-only")
+        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a 2-D float32 CUDA tensor")
+        if queries.shape[1] > 1 and queries.stride(1) != 1:
+            queries = queries.contiguous()
+        nq, qc = queries.shape
+        kout = min(int(k), self._n)
+        if out_idx is None:
+            out_idx = torch.empty((nq, kout), dtype=torch.int64, device=queries.device)
+        if out_dist is None:
+            out_dist = torch.empty((nq, kout), dtype=torch.float32, device=queries.device)
+        if nq and kout:
+            st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
+            check(_lib.lib().pn_query_device_f32(self._h, queries.data_ptr(), nq, qc,
+                                                 queries.stride(0) if nq > 1 else max(qc, 1), int(k),
+                                                 out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
+        return out_idx, out_dist

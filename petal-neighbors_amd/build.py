@@ -1,0 +1,81 @@
+"""Build recipe for libpetal_mi355x.so (gfx950 only; hipcc cross-compiles without a GPU).
+
+    python petal-neighbors_amd/build.py [--force] [--asm]
+
+Every translation unit is compiled in-tree to an object, then linked into
+``petal-neighbors_amd/libpetal_mi355x.so`` (git-ignored; it travels to the GPU
+box with the gpurun snapshot).  The exact-arithmetic units are compiled with
+``-ffp-contract=off`` so the reference's unfused fold (src/distance.rs:26-35)
+can never be contracted into an FMA; ``--asm`` also keeps the gfx950 ISA of
+those units under ``build/`` for the no-FMA audit in tests/test_build.py.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libpetal_mi355x.so")
+ARCH = "gfx950"
+
+# (source, extra flags)
+UNITS = [
+    ("index.hip", []),
+    ("exact_scan.hip", ["-ffp-contract=off"]),
+    ("select.hip", ["-ffp-contract=off"]),
+    ("pack.hip", []),
+    ("mfma_filter.hip", []),
+    ("metric.cpp", ["-ffp-contract=off"]),
+]
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built (no CPU fallback exists)")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    me = os.path.abspath(__file__)
+    for src, extra in UNITS:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp, me] + HEADERS):
+            lang = ["-x", "hip"] if src.endswith(".hip") else []
+            cmd = [cc] + COMMON + extra + lang + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        asm = os.path.join(BUILD, os.path.splitext(src)[0] + ".s")
+        if keep_asm and src.endswith(".hip") and (force or _stale(asm, [sp, me] + HEADERS)):
+            cmd = [cc] + COMMON + extra + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB, objs):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, keep_asm="--asm" in sys.argv, verbose=True))

@@ -1,0 +1,439 @@
+// exact_scan.hip -- exact Euclidean scan kernels for gfx950 (MI355X).
+//
+// Computes, for a tile of 64 queries x 64 corpus rows per workgroup step, the
+// distance of every (query, row) pair in EXACTLY the reference's operation
+// order -- petal-neighbors src/distance.rs:26-35:
+//     sum = 0;  for k in 0..D { diff = q[k] - p[k]; sum += diff * diff; }  sqrt(sum)
+// i.e. a strictly sequential fold, multiply and add rounded separately (never
+// fused), followed by a correctly rounded sqrt.  The kernels therefore replace
+// the leaf-scan inner loop of src/ball_tree.rs:217-226 / :275-282 with a
+// brute-force scan whose distances are bit-identical by construction.
+//
+// Used as: (1) the always-correct engine (PN_ENGINE_EXACT, f32 and f64),
+// (2) the per-query fallback when the MFMA filter cannot prove its result,
+// (3) query_radius (two-pass CSR) and distance::pairwise.
+//
+// Work decomposition (VALU-bound: 3 VALU ops per coordinate per pair):
+//   workgroup = 256 threads = 4 waves; tile = 64 queries x 64 rows;
+//   wave w owns queries [16w, 16w+16) of the tile (so a query's top-k state is
+//   touched by one wave only); lane (tq = lane&3, tp = lane>>2) accumulates a
+//   4 x 4 register block: queries 16w+4tq.., rows 4tp..;
+//   both operands are staged k-major in LDS in chunks of 32 coordinates, so any
+//   D works and each LDS b128 read feeds 12..48 VALU ops.
+//
+// Top-k: per (segment, query) an append buffer in HBM with a running threshold:
+//   a value enters if key < tau; when fewer than 64 free slots remain the owning
+//   wave ranks the buffer by (key, index), keeps the kp smallest and lowers tau
+//   to the kp-th.  Rows are scanned in ascending index order, so rejecting
+//   key == tau keeps exactly the (key, index)-smallest set.
+//
+// This translation unit must never contract a*b+c: it is compiled with
+// -ffp-contract=off AND every arithmetic function carries the pragma; the build
+// greps the ISA for v_fma/v_fmac/v_pk_fma in these kernels (tests/test_build.py).
+#include "pn_internal.h"
+
+namespace pn {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+__device__ __forceinline__ uint32_t dist_key(float d) {
+    return (d != d) ? KeyOf<float>::kNaN : __float_as_uint(d);
+}
+__device__ __forceinline__ uint64_t dist_key(double d) {
+    return (d != d) ? KeyOf<double>::kNaN : (uint64_t)__double_as_longlong(d);
+}
+__device__ __forceinline__ float pn_sqrt(float x) { return sqrtf(x); }   // correctly rounded (default hipcc)
+__device__ __forceinline__ double pn_sqrt(double x) { return sqrt(x); }
+
+__device__ __forceinline__ uint32_t bcast_lane(uint32_t v, int ln) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, ln);
+}
+__device__ __forceinline__ uint64_t bcast_lane(uint64_t v, int ln) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, ln);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), ln);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// wave-local ordering point for LDS / HBM traffic that other lanes of the SAME
+// workgroup read back (candidate buffers, cnt/tau words)
+__device__ __forceinline__ void wg_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---------------------------------------------------------------------------
+// One 64 x 64 tile: acc[qi][pi] = fold over k of (q - p)^2, k ascending.
+// Pt/Qt point at row 0 of the tile; rows are zero padded to a multiple of 8
+// coordinates and row counts to a multiple of 64, so loads need no row guard.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void stage_chunk(const T *__restrict__ src, size_t ld, int kc0, int dim,
+                                            T (*dst)[kTileQ], int tid) {
+    using V = typename Vec4<T>::type;
+    const int row = tid & 63;
+    const int kq = (tid >> 6) * 8;
+    const int k0 = kc0 + kq;
+    T v[8];
+    if (k0 < dim) {  // dim <= ld, groups of 8 never straddle the padded row end
+        const T *p = src + (size_t)row * ld + k0;
+        V a = *reinterpret_cast<const V *>(p);
+        V b = *reinterpret_cast<const V *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // coordinates at or beyond `dim` do not take part (zip truncation, src/distance.rs:27-28)
+        dst[kq + j][row] = (k0 + j < dim) ? v[j] : (T)0;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ldp, const T *__restrict__ Qt,
+                                             size_t ldq, int dim, bool stage_q, T (&acc)[4][4],
+                                             T (*Qs)[kTileQ], T (*Ps)[kTileP], int tid, int qb, int pb) {
+#pragma clang fp contract(off)
+    using V = typename Vec4<T>::type;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (T)0;
+
+    for (int kc0 = 0; kc0 < dim; kc0 += kChunkK) {
+        __syncthreads();  // previous chunk fully consumed
+        if (stage_q || kc0 > 0 || dim > kChunkK) stage_chunk<T>(Qt, ldq, kc0, dim, Qs, tid);
+        stage_chunk<T>(Pt, ldp, kc0, dim, Ps, tid);
+        __syncthreads();
+        const int klen = (dim - kc0 < kChunkK) ? (dim - kc0) : kChunkK;
+        for (int k = 0; k < klen; ++k) {
+            const V qv = *reinterpret_cast<const V *>(&Qs[k][qb]);
+            const V pv = *reinterpret_cast<const V *>(&Ps[k][pb]);
+            const T q[4] = {qv.x, qv.y, qv.z, qv.w};
+            const T p[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const T diff = q[a] - p[b];   // v1 - v2 with v1 = query (src/ball_tree.rs:218)
+                    const T sq = diff * diff;
+                    acc[a][b] = acc[a][b] + sq;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rank-and-keep compaction of one query's candidate buffer by its owning wave.
+// ---------------------------------------------------------------------------
+template <typename KeyT, int M>
+__device__ __forceinline__ void compact_query(KeyT *__restrict__ ckey, uint32_t *__restrict__ cidx, size_t base,
+                                              uint32_t n, uint32_t kp, int lane, KeyT *tau_slot,
+                                              uint32_t *cnt_slot, KeyT key_max) {
+    KeyT key[M];
+    uint32_t ix[M], rank[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const uint32_t slot = m * 64 + lane;
+        const bool v = slot < n;
+        key[m] = v ? ckey[base + slot] : key_max;
+        ix[m] = v ? cidx[base + slot] : 0xFFFFFFFFu;
+        rank[m] = 0;
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < M; ++m2) {
+        int lim = (int)n - m2 * 64;
+        lim = lim > 64 ? 64 : lim;
+        for (int ln = 0; ln < lim; ++ln) {
+            const KeyT bk = bcast_lane(key[m2], ln);
+            const uint32_t bi = bcast_lane(ix[m2], ln);
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                rank[m] += ((bk < key[m]) || (bk == key[m] && bi < ix[m])) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        if ((uint32_t)(m * 64 + lane) < n && rank[m] < kp) {
+            ckey[base + rank[m]] = key[m];
+            cidx[base + rank[m]] = ix[m];
+            if (rank[m] == kp - 1) *tau_slot = key[m];
+        }
+    }
+    if (lane == 0) *cnt_slot = n < kp ? n : kp;
+    wg_fence();
+}
+
+// ---------------------------------------------------------------------------
+// k-NN scan.  grid = (query tiles, segments), block = 256.
+// ---------------------------------------------------------------------------
+template <typename T, int M>
+__global__ __launch_bounds__(256) void exact_knn_kernel(
+    const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq,
+    uint32_t kp, size_t seg_len, typename KeyOf<T>::type *__restrict__ ckey, uint32_t *__restrict__ cidx,
+    uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad) {
+    using KeyT = typename KeyOf<T>::type;
+    constexpr uint32_t CAP = 64u * M;
+    constexpr KeyT KMAX = KeyOf<T>::kMax;
+    __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
+    __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
+    __shared__ KeyT taus[kTileQ];
+    __shared__ uint32_t cnts[kTileQ];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tq = lane & 3, tp = lane >> 2;
+    const int qb = wave * 16 + tq * 4;  // first of this lane's 4 queries within the tile
+    const int pb = tp * 4;              // first of this lane's 4 rows within the tile
+    const size_t q0 = (size_t)blockIdx.x * kTileQ;
+    const size_t seg = blockIdx.y;
+    const size_t p_begin = seg * seg_len;
+    const size_t p_end = (p_begin + seg_len < n) ? p_begin + seg_len : n;
+
+    if (tid < kTileQ) { taus[tid] = KMAX; cnts[tid] = 0; }
+    __syncthreads();
+
+    const T *Qt = Q + q0 * ldq;
+    const size_t cbase0 = (seg * nq_pad + q0) * (size_t)CAP;
+    bool first = true;
+    for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
+        T acc[4][4];
+        compute_tile<T>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        first = false;
+
+        KeyT key[4][4];
+        KeyT tau_r[4];
+        bool anyp = false;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            tau_r[a] = taus[qb + a];
+            const bool qv = (q0 + qb + a) < (size_t)nq;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool v = qv && (p0 + pb + b) < p_end;
+                const KeyT kk = v ? dist_key(pn_sqrt(acc[a][b])) : KMAX;
+                key[a][b] = kk;
+                anyp |= kk < tau_r[a];
+            }
+        }
+        if (__any(anyp)) {  // wave-uniform slow path: append, then compact where nearly full
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (key[a][b] < tau_r[a]) {
+                        const uint32_t slot = atomicAdd(&cnts[qb + a], 1u);
+                        const size_t o = cbase0 + (size_t)(qb + a) * CAP + slot;
+                        ckey[o] = key[a][b];
+                        cidx[o] = (uint32_t)(p0 + pb + b);
+                    }
+            wg_fence();
+            for (int j = 0; j < 16; ++j) {
+                const int qj = wave * 16 + j;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnts[qj]);
+                if (c + 64u > CAP)  // fewer than 64 free slots: a full tile might not fit
+                    compact_query<KeyT, M>(ckey, cidx, cbase0 + (size_t)qj * CAP, c, kp, lane, &taus[qj],
+                                           &cnts[qj], KMAX);
+            }
+        }
+    }
+    // leave at most kp candidates per (segment, query) for the select kernel
+    for (int j = 0; j < 16; ++j) {
+        const int qj = wave * 16 + j;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnts[qj]);
+        if (c > kp)
+            compact_query<KeyT, M>(ckey, cidx, cbase0 + (size_t)qj * CAP, c, kp, lane, &taus[qj], &cnts[qj],
+                                   KMAX);
+    }
+    if (lane < 16) {
+        const int qj = wave * 16 + lane;
+        ccnt[seg * nq_pad + q0 + qj] = cnts[qj];
+        ctau[seg * nq_pad + q0 + qj] = taus[qj];
+    }
+}
+
+template <typename T>
+static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
+                                   int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
+    using KeyT = typename KeyOf<T>::type;
+    dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
+    auto *ck = static_cast<KeyT *>(cb.keys);
+    auto *ct = static_cast<KeyT *>(cb.tau);
+#define PN_LAUNCH(MM)                                                                                    \
+    hipLaunchKernelGGL((exact_knn_kernel<T, MM>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,          \
+                       (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad)
+    switch (cb.cap / 64) {
+        case 2: PN_LAUNCH(2); break;
+        case 4: PN_LAUNCH(4); break;
+        case 8: PN_LAUNCH(8); break;
+        case 16: PN_LAUNCH(16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef PN_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
+    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+}
+hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
+    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+}
+
+// ---------------------------------------------------------------------------
+// query_radius: { i : distance(q, p_i) < r } (strict, src/ball_tree.rs:277),
+// ascending index.  Pass 1 counts per (query, segment); the host turns counts
+// into offsets; pass 2 writes indices in row order: within a tile the 16 lanes
+// that share a query scan their per-lane counts with stride-4 shuffles.
+// ---------------------------------------------------------------------------
+template <typename T, bool FILL>
+__global__ __launch_bounds__(256) void exact_radius_kernel(
+    const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq, T r,
+    size_t seg_len, int nseg, uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
+    uint64_t *__restrict__ fill, uint64_t index_base) {
+    __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
+    __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
+    __shared__ uint32_t cnts[kTileQ];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tq = lane & 3, tp = lane >> 2;
+    const int qb = wave * 16 + tq * 4, pb = tp * 4;
+    const size_t q0 = (size_t)blockIdx.x * kTileQ;
+    const size_t seg = blockIdx.y;
+    const size_t p_begin = seg * seg_len;
+    const size_t p_end = (p_begin + seg_len < n) ? p_begin + seg_len : n;
+    if (tid < kTileQ) cnts[tid] = 0;
+    __syncthreads();
+
+    const T *Qt = Q + q0 * ldq;
+    uint64_t obase[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const size_t q = q0 + qb + a;
+        obase[a] = (FILL && q < (size_t)nq) ? offsets[q * nseg + seg] : 0;
+    }
+    bool first = true;
+    for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
+        T acc[4][4];
+        compute_tile<T>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        first = false;
+        uint32_t mask[4];
+        bool anyp = false;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bool qv = (q0 + qb + a) < (size_t)nq;
+            uint32_t m = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool v = qv && (p0 + pb + b) < p_end;
+                const T d = pn_sqrt(acc[a][b]);
+                if (v && d < r) m |= 1u << b;  // NaN distances never match
+            }
+            mask[a] = m;
+            anyp |= m != 0;
+        }
+        if (!__any(anyp)) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const uint32_t c = __popc(mask[a]);
+            // inclusive scan over the 16 lanes (stride 4) that share this query
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 4; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d);
+                if (lane >= d) inc += t;
+            }
+            const uint32_t total = __shfl(inc, 60 + tq);
+            if (total == 0) continue;
+            const uint32_t before = cnts[qb + a];  // written only by this wave
+            if (FILL) {
+                uint64_t pos = obase[a] + before + (inc - c);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (mask[a] & (1u << b)) fill[pos++] = index_base + (uint64_t)(p0 + pb + b);
+            }
+            wg_fence();
+            if (tp == 15) cnts[qb + a] = before + total;
+            wg_fence();
+        }
+    }
+    if (!FILL && lane < 16) {
+        const size_t q = q0 + wave * 16 + lane;
+        if (q < (size_t)nq) counts[q * nseg + seg] = cnts[wave * 16 + lane];
+    }
+}
+
+template <typename T>
+static hipError_t launch_exact_radius(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
+                                      T r, size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offsets,
+                                      uint64_t *fill, uint64_t index_base, hipStream_t s) {
+    dim3 grid((unsigned)(round_up((size_t)nq, kTileQ) / kTileQ), (unsigned)nseg), block(256);
+    if (fill)
+        hipLaunchKernelGGL((exact_radius_kernel<T, true>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r, seg_len,
+                           nseg, counts, offsets, fill, index_base);
+    else
+        hipLaunchKernelGGL((exact_radius_kernel<T, false>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r,
+                           seg_len, nseg, counts, offsets, fill, index_base);
+    return hipGetLastError();
+}
+hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
+                                   size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, hipStream_t s) {
+    return launch_exact_radius<float>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
+                                      index_base, s);
+}
+hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
+                                   size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, hipStream_t s) {
+    return launch_exact_radius<double>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
+                                       index_base, s);
+}
+
+// ---------------------------------------------------------------------------
+// distance::pairwise (src/distance.rs:58-74): out[i][j] = distance(x_i, x_j),
+// zero diagonal.  (a-b)^2 == (b-a)^2 exactly, so computing both triangles
+// equals the reference's mirrored fill.  grid = (tiles, tiles).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void exact_pairwise_kernel(const T *__restrict__ X, size_t n, int dim, size_t ld,
+                                                             T *__restrict__ out) {
+    __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
+    __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tq = lane & 3, tp = lane >> 2;
+    const int qb = wave * 16 + tq * 4, pb = tp * 4;
+    const size_t q0 = (size_t)blockIdx.x * kTileQ, p0 = (size_t)blockIdx.y * kTileP;
+    T acc[4][4];
+    compute_tile<T>(X + p0 * ld, ld, X + q0 * ld, ld, dim, true, acc, Qs, Ps, tid, qb, pb);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const size_t i = q0 + qb + a;
+        if (i >= n) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const size_t j = p0 + pb + b;
+            if (j < n) out[i * n + j] = (i == j) ? (T)0 : pn_sqrt(acc[a][b]);
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_exact_pairwise(const T *X, size_t n, int dim, size_t ld, T *out, hipStream_t s) {
+    const unsigned t = (unsigned)(round_up(n, kTileQ) / kTileQ);
+    dim3 grid(t, t), block(256);
+    hipLaunchKernelGGL((exact_pairwise_kernel<T>), grid, block, 0, s, X, n, dim, ld, out);
+    return hipGetLastError();
+}
+hipError_t launch_exact_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *out, hipStream_t s) {
+    return launch_exact_pairwise<float>(X, n, dim, ld, out, s);
+}
+hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *out, hipStream_t s) {
+    return launch_exact_pairwise<double>(X, n, dim, ld, out, s);
+}
+
+}  // namespace pn

@@ -1,0 +1,833 @@
+// index.hip -- the C ABI (include/petal_mi355x.h): index lifetime, host <-> HBM
+// staging, engine selection and kernel orchestration.  gfx950 / ROCm only.
+// No CPU compute path exists here: without a GPU every compute entry point
+// returns PN_ERR_DEVICE.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/petal_mi355x.h"
+#include "pn_internal.h"
+
+using namespace pn;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? PN_ERR_NOMEM : PN_ERR_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                 \
+    } while (0)
+#define PNCHK(expr)                 \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != PN_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *pn_last_error(void) { return g_err.c_str(); }
+extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }
+extern "C" const char *pn_strerror(int code) {
+    switch (code) {
+        case PN_OK: return "ok";
+        case PN_ERR_EMPTY: return "array is empty";                         // src/lib.rs:12
+        case PN_ERR_NOT_CONTIGUOUS: return "array is not contiguous in memory";  // src/lib.rs:14
+        case PN_ERR_INVALID: return "invalid argument";
+        case PN_ERR_DEVICE: return "GPU device error";
+        case PN_ERR_NOMEM: return "out of memory";
+        case PN_ERR_UNSUPPORTED: return "unsupported";
+        case PN_ERR_EMPTY_MATRIX: return "empty matrix";                    // src/ball_tree.rs:582
+        default: return "unknown error";
+    }
+}
+extern "C" int pn_device_count(int *count) {
+    if (!count) return fail(PN_ERR_INVALID, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(PN_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// index object
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes && p) return PN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(PN_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        bytes = want;
+        return PN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct pn_index {
+    int device = 0;
+    int elem_bytes = 4;
+    size_t n = 0, dim = 0, ld = 0, n_pad = 0;
+    void *d_pts = nullptr;   // [n_pad][ld], zero padded
+    float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
+    bool mfma_ok = false;
+    hipStream_t stream = nullptr;
+    // options
+    int engine = PN_ENGINE_AUTO;
+    int opt_segments = 0;
+    uint64_t index_base = 0;
+    int profile = 0;
+    int filter_slots = 0;
+    // per-call scratch, serialised by `mu`
+    mutable std::mutex mu;
+    mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
+    mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau;
+    mutable pn_stats stats{};
+    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+static int check_device(int device) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0)
+        return fail(PN_ERR_DEVICE, "no usable GPU (hipGetDeviceCount: %s); this library has no CPU path",
+                    hipGetErrorString(e));
+    if (device < 0 || device >= c) return fail(PN_ERR_INVALID, "device %d out of range [0,%d)", device, c);
+    return PN_OK;
+}
+
+static float mfma_alpha(size_t dim) {
+    // (2(D+2)+8) * 2^-24: covers the (D+2)-step MFMA fma chain twice (see mfma_filter.hip)
+    return (float)((2.0 * (double)(dim + 2) + 8.0) * 5.9604644775390625e-08);
+}
+
+template <typename T>
+static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStream_t s) {
+    // d_src: device rows [n][row_stride] (inner stride 1) -> padded layout + norms
+    const size_t bytes = ix->n_pad * ix->ld * sizeof(T);
+    HIPCHK(hipMalloc(&ix->d_pts, bytes ? bytes : 256));
+    if (sizeof(T) == 4)
+        HIPCHK(launch_pack_rows_f32((const float *)d_src, ix->n, ix->dim, row_stride, (float *)ix->d_pts, ix->n_pad,
+                                    ix->ld, s));
+    else
+        HIPCHK(launch_pack_rows_f64((const double *)d_src, ix->n, ix->dim, row_stride, (double *)ix->d_pts,
+                                    ix->n_pad, ix->ld, s));
+    ix->mfma_ok = false;
+    if (sizeof(T) == 4) {
+        HIPCHK(hipMalloc((void **)&ix->d_norm, ix->n_pad * sizeof(float)));
+        uint32_t *d_flag = nullptr;
+        HIPCHK(hipMalloc((void **)&d_flag, sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s));
+        HIPCHK(launch_row_norms_f32((const float *)ix->d_pts, ix->n_pad, ix->n, (int)ix->dim, ix->ld,
+                                    mfma_alpha(ix->dim), ix->d_norm, d_flag, s));
+        uint32_t h_flag = 0;
+        HIPCHK(hipMemcpyAsync(&h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(d_flag);
+        ix->mfma_ok = (h_flag == 0) && mfma_supported((int)ix->dim, ix->ld) && ix->n < 0xFFFFFFF0ull;
+    } else {
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return PN_OK;
+}
+
+static int validate_create(const void *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                           ptrdiff_t col_stride, pn_index **out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_rows == 0) return fail(PN_ERR_EMPTY, "array is empty");  // src/ball_tree.rs:44-46
+    // only the inner stride is inspected, like row(0).is_standard_layout() (src/ball_tree.rs:47)
+    if (n_cols > 1 && col_stride != 1) return fail(PN_ERR_NOT_CONTIGUOUS, "array is not contiguous in memory");
+    if (n_cols == 0 && n_rows >= 2) return fail(PN_ERR_EMPTY_MATRIX, "empty matrix");  // src/ball_tree.rs:582
+    if (!points && n_cols) return fail(PN_ERR_INVALID, "points is NULL");
+    if (row_stride < 0) return fail(PN_ERR_UNSUPPORTED, "negative row stride");
+    if (n_rows > 1 && (size_t)row_stride < n_cols && n_cols > 0 && row_stride != 0)
+        return fail(PN_ERR_UNSUPPORTED, "overlapping rows (row_stride < n_cols)");
+    if (n_rows >= 0xFFFFFFF0ull) return fail(PN_ERR_UNSUPPORTED, "more than 2^32-16 rows per index: shard the corpus");
+    return PN_OK;
+}
+
+template <typename T>
+static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                            ptrdiff_t col_stride, int device, pn_index **out) {
+    PNCHK(validate_create(points, n_rows, n_cols, row_stride, col_stride, out));
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    pn_index *ix = new (std::nothrow) pn_index();
+    if (!ix) return fail(PN_ERR_NOMEM, "host allocation failed");
+    ix->device = device;
+    ix->elem_bytes = (int)sizeof(T);
+    ix->n = n_rows;
+    ix->dim = n_cols;
+    ix->ld = round_up(n_cols ? n_cols : 1, kRowAlign);
+    ix->n_pad = round_up(n_rows, kRowPad);
+    int rc = PN_OK;
+    T *d_tmp = nullptr;
+    do {
+        if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "hipStreamCreate failed");
+            break;
+        }
+        const size_t tmp_elems = n_rows * (n_cols ? n_cols : 1);
+        hipError_t e = hipMalloc((void **)&d_tmp, tmp_elems * sizeof(T));
+        if (e != hipSuccess) { rc = fail(PN_ERR_NOMEM, "hipMalloc staging: %s", hipGetErrorString(e)); break; }
+        if (n_cols) {
+            // the host array is read once, here, and never retained (CowArray borrow, src/ball_tree.rs:42)
+            if (n_rows == 1 || (size_t)row_stride == n_cols)
+                e = hipMemcpy(d_tmp, points, tmp_elems * sizeof(T), hipMemcpyHostToDevice);
+            else if (row_stride == 0) {
+                for (size_t r = 0; r < n_rows && e == hipSuccess; ++r)
+                    e = hipMemcpy(d_tmp + r * n_cols, points, n_cols * sizeof(T), hipMemcpyHostToDevice);
+            } else
+                e = hipMemcpy2D(d_tmp, n_cols * sizeof(T), points, (size_t)row_stride * sizeof(T),
+                                n_cols * sizeof(T), n_rows, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { rc = fail(PN_ERR_DEVICE, "H2D copy: %s", hipGetErrorString(e)); break; }
+        }
+        rc = finish_index<T>(ix, d_tmp, n_cols, ix->stream);
+    } while (0);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc != PN_OK) {
+        pn_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return PN_OK;
+}
+
+extern "C" int pn_index_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                   ptrdiff_t col_stride, int device, pn_index **out) {
+    return create_from_host<float>(points, n_rows, n_cols, row_stride, col_stride, device, out);
+}
+extern "C" int pn_index_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                   ptrdiff_t col_stride, int device, pn_index **out) {
+    return create_from_host<double>(points, n_rows, n_cols, row_stride, col_stride, device, out);
+}
+
+extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
+                                          int device, void *stream, pn_index **out) {
+    PNCHK(validate_create(d_points, n_rows, n_cols, (ptrdiff_t)row_stride, 1, out));
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    pn_index *ix = new (std::nothrow) pn_index();
+    if (!ix) return fail(PN_ERR_NOMEM, "host allocation failed");
+    ix->device = device;
+    ix->elem_bytes = 4;
+    ix->n = n_rows;
+    ix->dim = n_cols;
+    ix->ld = round_up(n_cols ? n_cols : 1, kRowAlign);
+    ix->n_pad = round_up(n_rows, kRowPad);
+    int rc = PN_OK;
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(PN_ERR_DEVICE, "hipStreamCreate failed");
+    if (rc == PN_OK) {
+        // order after the producer of d_points on `stream`
+        hipStream_t src = (hipStream_t)stream;
+        if (hipStreamSynchronize(src) != hipSuccess) rc = fail(PN_ERR_DEVICE, "stream sync failed");
+    }
+    if (rc == PN_OK) rc = finish_index<float>(ix, d_points, row_stride, ix->stream);
+    if (rc != PN_OK) {
+        pn_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return PN_OK;
+}
+
+extern "C" void pn_index_destroy(pn_index *ix) {
+    if (!ix) return;
+    DeviceGuard g(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    DevBuf *bufs[] = {&ix->w_q, &ix->w_qnorm, &ix->w_keys, &ix->w_idx, &ix->w_cnt, &ix->w_tau, &ix->w_flags,
+                      &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
+                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau};
+    for (DevBuf *b : bufs) b->release();
+    if (ix->d_pts) (void)hipFree(ix->d_pts);
+    if (ix->d_norm) (void)hipFree(ix->d_norm);
+    hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
+    if (!ix || !out) return fail(PN_ERR_INVALID, "NULL argument");
+    out->n_points = ix->n;
+    out->dim = ix->dim;
+    out->row_stride_device = ix->ld;
+    out->elem_bytes = ix->elem_bytes;
+    out->device = ix->device;
+    out->mfma_eligible = ix->mfma_ok ? 1 : 0;
+    out->reserved = 0;
+    return PN_OK;
+}
+
+extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    switch (option) {
+        case PN_OPT_ENGINE:
+            if (value < PN_ENGINE_AUTO || value > PN_ENGINE_MFMA) return fail(PN_ERR_INVALID, "bad engine %lld", (long long)value);
+            if (value == PN_ENGINE_MFMA && !ix->mfma_ok)
+                return fail(PN_ERR_UNSUPPORTED, "the MFMA filter cannot serve this index (f64, non-finite norms or unsupported shape)");
+            ix->engine = (int)value;
+            return PN_OK;
+        case PN_OPT_SEGMENTS:
+            if (value < 0 || value > 4096) return fail(PN_ERR_INVALID, "bad segment count");
+            ix->opt_segments = (int)value;
+            return PN_OK;
+        case PN_OPT_INDEX_BASE: ix->index_base = (uint64_t)value; return PN_OK;
+        case PN_OPT_PROFILE: ix->profile = value ? 1 : 0; return PN_OK;
+        case PN_OPT_FILTER_SLOTS:
+            if (value < 0 || value > 960) return fail(PN_ERR_INVALID, "bad filter slot count");
+            ix->filter_slots = (int)value;
+            return PN_OK;
+        default: return fail(PN_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C" int pn_index_get_stats(const pn_index *ix, pn_stats *out, int reset) {
+    if (!ix || !out) return fail(PN_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *out = ix->stats;
+    if (reset) ix->stats = pn_stats{};
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// planning helpers
+// ---------------------------------------------------------------------------
+static int pick_cap(size_t kp) {  // slots per (segment, query): multiple of 64, >= kp + 64
+    const int caps[] = {128, 256, 512, 1024};
+    for (int c : caps)
+        if ((size_t)c >= kp + 64) return c;
+    return 0;
+}
+
+struct ScanPlan {
+    int nseg;
+    size_t seg_len;
+};
+
+static ScanPlan plan_segments(size_t n, size_t q_tiles, int cap, int forced, size_t min_seg_rows, size_t max_entries) {
+    size_t max_seg = max_entries / (size_t)cap;  // select kernel LDS budget
+    if (max_seg < 1) max_seg = 1;
+    size_t nseg;
+    if (forced > 0) {
+        nseg = (size_t)forced;
+    } else {
+        const size_t target_wgs = 2048;
+        nseg = (target_wgs + q_tiles - 1) / q_tiles;
+        const size_t by_rows = (n + min_seg_rows - 1) / min_seg_rows;
+        if (nseg > by_rows) nseg = by_rows;
+    }
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    size_t seg_len = round_up((n + nseg - 1) / nseg, (size_t)kRowPad);
+    if (seg_len == 0) seg_len = kRowPad;
+    nseg = (n + seg_len - 1) / seg_len;
+    if (nseg < 1) nseg = 1;
+    return ScanPlan{(int)nseg, seg_len};
+}
+
+static int ensure_events(const pn_index *ix) {
+    if (ix->ev0) return PN_OK;
+    HIPCHK(hipEventCreate(&ix->ev0));
+    HIPCHK(hipEventCreate(&ix->ev1));
+    HIPCHK(hipEventCreate(&ix->ev2));
+    HIPCHK(hipEventCreate(&ix->ev3));
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// k-NN
+// ---------------------------------------------------------------------------
+template <typename T> struct Ops;
+template <> struct Ops<float> {
+    static hipError_t pack(const float *s, size_t n, size_t c, size_t rs, float *d, size_t np, size_t ld, hipStream_t st) {
+        return launch_pack_rows_f32(s, n, c, rs, d, np, ld, st);
+    }
+    static hipError_t knn(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, int kp,
+                          size_t seg_len, const CandBuf &cb, hipStream_t s) {
+        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+    }
+    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, hipStream_t s) {
+        return launch_select_exact_f32(cb, nq, kout, base, io, dd, s);
+    }
+};
+template <> struct Ops<double> {
+    static hipError_t pack(const double *s, size_t n, size_t c, size_t rs, double *d, size_t np, size_t ld, hipStream_t st) {
+        return launch_pack_rows_f64(s, n, c, rs, d, np, ld, st);
+    }
+    static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
+                          size_t seg_len, const CandBuf &cb, hipStream_t s) {
+        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+    }
+    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, hipStream_t s) {
+        return launch_select_exact_f64(cb, nq, kout, base, io, dd, s);
+    }
+};
+
+// exact engine on packed queries Qp [nq_pad][ld]; results to d_idx/d_dist [nq][kout]
+template <typename T>
+static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
+                     uint64_t *d_idx, T *d_dist, hipStream_t s, bool second_set, bool hot) {
+    using KeyT = typename KeyOf<T>::type;
+    const int cap = pick_cap(kout);
+    if (!cap)
+        return fail(PN_ERR_UNSUPPORTED, "k = %zu exceeds the single-pass limit of 960 neighbours", kout);
+    const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, cap, ix->opt_segments, 4096, 4096);
+    DevBuf &bk = second_set ? ix->w2_keys : ix->w_keys;
+    DevBuf &bi = second_set ? ix->w2_idx : ix->w_idx;
+    DevBuf &bc = second_set ? ix->w2_cnt : ix->w_cnt;
+    DevBuf &bt = second_set ? ix->w2_tau : ix->w_tau;
+    const size_t slots = (size_t)pl.nseg * nq_pad * (size_t)cap;
+    PNCHK(bk.ensure(slots * sizeof(KeyT)));
+    PNCHK(bi.ensure(slots * sizeof(uint32_t)));
+    PNCHK(bc.ensure((size_t)pl.nseg * nq_pad * sizeof(uint32_t)));
+    PNCHK(bt.ensure((size_t)pl.nseg * nq_pad * sizeof(KeyT)));
+    CandBuf cb{bk.p, (uint32_t *)bi.p, (uint32_t *)bc.p, bt.p, nq_pad, pl.nseg, cap};
+    const bool prof = hot && ix->profile;
+    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kout, pl.seg_len, cb, s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
+    HIPCHK(Ops<T>::select(cb, (int)nq, (int)kout, ix->index_base, d_idx, d_dist, s));
+    if (prof) {
+        HIPCHK(hipEventSynchronize(ix->ev1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        ix->stats.hot_ms += ms;
+        ix->stats.hot_launches += 1;
+    }
+    return PN_OK;
+}
+
+static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
+                    float *d_dist, hipStream_t s);
+
+template <typename T>
+static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, T *d_dist, hipStream_t s) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const size_t kout = k < ix->n ? k : ix->n;
+    if (nq == 0 || kout == 0) return PN_OK;  // k == 0 -> empty result (src/ball_tree.rs:106-108)
+    if (!d_q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
+    if (!d_idx || !d_dist) return fail(PN_ERR_INVALID, "output buffer is NULL");
+    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!s) s = ix->stream;
+    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;  // zip truncation (src/distance.rs:27-28)
+    if (ix->profile) {
+        PNCHK(ensure_events(ix));
+        HIPCHK(hipEventRecord(ix->ev2, s));
+    }
+    const size_t chunk = 1u << 18;
+    for (size_t qs = 0; qs < nq; qs += chunk) {
+        const size_t nqc = (nq - qs < chunk) ? nq - qs : chunk;
+        const size_t nq_pad = round_up(nqc, (size_t)kRowPad);
+        PNCHK(ix->w_q.ensure(nq_pad * ix->ld * sizeof(T)));
+        T *Qp = (T *)ix->w_q.p;
+        HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
+        uint64_t *oi = d_idx + qs * kout;
+        T *od = d_dist + qs * kout;
+        bool use_mfma = false;
+        if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
+            // the filter keeps kout + margin candidates per (segment, query) in at most 960 slots
+            use_mfma = kout <= 896;
+            if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
+        }
+        if (use_mfma)
+            PNCHK(run_mfma(ix, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, s));
+        else
+            PNCHK(run_exact<T>(ix, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, s, false, true));
+        ix->stats.queries += nqc;
+    }
+    if (ix->profile) {
+        HIPCHK(hipEventRecord(ix->ev3, s));
+        HIPCHK(hipEventSynchronize(ix->ev3));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ix->ev2, ix->ev3));
+        ix->stats.last_call_ms = ms;
+    }
+    return PN_OK;
+}
+
+// MFMA filter -> exact re-rank -> verification -> exact fallback for flagged queries
+static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
+                    float *d_dist, hipStream_t s) {
+    // candidate slots kept per (segment, query)
+    size_t kp = ix->filter_slots > 0 ? (size_t)ix->filter_slots : kout + (kout < 16 ? 6 : kout / 4 + 4);
+    if (kp < kout) kp = kout;
+    int cap = pick_cap(kp);
+    if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
+    // scaled query norms (same kernel as the corpus norms)
+    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
+    PNCHK(ix->w_misc.ensure(64));
+    uint32_t *d_nflag = (uint32_t *)ix->w_misc.p;           // [0] = flagged count, [1] = non-finite query norms
+    uint64_t *d_ncand = (uint64_t *)((char *)ix->w_misc.p + 8);
+    uint32_t *d_nsel = (uint32_t *)((char *)ix->w_misc.p + 16);
+    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
+    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
+                                d_nflag + 1, s));
+    const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192);
+    MfmaPlan plan{sp.nseg, sp.seg_len, (int)kp, cap};
+    const size_t slots = (size_t)plan.nseg * nq_pad * (size_t)cap;
+    PNCHK(ix->w_keys.ensure(slots * sizeof(uint32_t)));
+    PNCHK(ix->w_idx.ensure(slots * sizeof(uint32_t)));
+    PNCHK(ix->w_cnt.ensure((size_t)plan.nseg * nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_tau.ensure((size_t)plan.nseg * nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));
+    CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_idx.p, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, plan.nseg, cap};
+    const bool prof = ix->profile;
+    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld, Qp,
+                                  (const float *)ix->w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
+    HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
+                                    (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_flags.p, d_nflag,
+                                    d_ncand, s));
+    struct { uint32_t nflag, qnonfinite; uint64_t ncand; } h{};
+    HIPCHK(hipMemcpyAsync(&h, ix->w_misc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (prof) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        ix->stats.hot_ms += ms;
+        ix->stats.hot_launches += 1;
+    }
+    ix->stats.candidates += h.ncand;
+    if (h.nflag) {
+        // re-run the unproven queries on the exact engine
+        const size_t nf = h.nflag;
+        const size_t nf_pad = round_up(nf, (size_t)kRowPad);
+        PNCHK(ix->w_sel.ensure(nq * sizeof(uint32_t)));
+        PNCHK(ix->w_fq.ensure(nf_pad * ix->ld * sizeof(float)));
+        PNCHK(ix->w_fidx.ensure(nf * kout * sizeof(uint64_t)));
+        PNCHK(ix->w_fdist.ensure(nf * kout * sizeof(float)));
+        HIPCHK(hipMemsetAsync(ix->w_fq.p, 0, nf_pad * ix->ld * sizeof(float), s));
+        HIPCHK(launch_compact_flags((const uint32_t *)ix->w_flags.p, (int)nq, (uint32_t *)ix->w_sel.p, d_nsel, s));
+        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_sel.p, (int)nf, (float *)ix->w_fq.p, s));
+        PNCHK(run_exact<float>(ix, (const float *)ix->w_fq.p, nf, nf_pad, (int)ix->dim, kout, (uint64_t *)ix->w_fidx.p,
+                               (float *)ix->w_fdist.p, s, true, false));
+        HIPCHK(launch_scatter_results_f32((const uint64_t *)ix->w_fidx.p, (const float *)ix->w_fdist.p,
+                                          (const uint32_t *)ix->w_sel.p, (int)nf, (int)kout, d_idx, d_dist, s));
+        ix->stats.fallback_queries += nf;
+    }
+    return PN_OK;
+}
+
+extern "C" int pn_query_device_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                                   size_t k, uint64_t *d_idx, float *d_dist, void *stream) {
+    return query_device_impl<float>(ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, (hipStream_t)stream);
+}
+extern "C" int pn_query_device_f64(const pn_index *ix, const double *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                                   size_t k, uint64_t *d_idx, double *d_dist, void *stream) {
+    return query_device_impl<double>(ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, (hipStream_t)stream);
+}
+
+// host staging: queries H2D, results D2H
+template <typename T>
+static int upload_rows(const T *h, size_t rows, size_t cols, ptrdiff_t row_stride, T **d_out) {
+    *d_out = nullptr;
+    const size_t c = cols ? cols : 1;
+    HIPCHK(hipMalloc((void **)d_out, rows * c * sizeof(T)));
+    if (cols == 0) return PN_OK;
+    if (row_stride < 0) return fail(PN_ERR_UNSUPPORTED, "negative row stride");
+    if (rows == 1 || (size_t)row_stride == cols)
+        HIPCHK(hipMemcpy(*d_out, h, rows * cols * sizeof(T), hipMemcpyHostToDevice));
+    else if (row_stride == 0) {
+        for (size_t r = 0; r < rows; ++r)
+            HIPCHK(hipMemcpy(*d_out + r * cols, h, cols * sizeof(T), hipMemcpyHostToDevice));
+    } else
+        HIPCHK(hipMemcpy2D(*d_out, cols * sizeof(T), h, (size_t)row_stride * sizeof(T), cols * sizeof(T), rows,
+                           hipMemcpyHostToDevice));
+    return PN_OK;
+}
+
+template <typename T>
+static int query_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, size_t k,
+                           uint64_t *idx_out, T *dist_out) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const size_t kout = k < ix->n ? k : ix->n;
+    if (nq == 0 || kout == 0) return PN_OK;
+    if (!q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
+    if (!idx_out || !dist_out) return fail(PN_ERR_INVALID, "output buffer is NULL");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    T *d_q = nullptr, *d_dist = nullptr;
+    uint64_t *d_idx = nullptr;
+    int rc = upload_rows<T>(q, nq, q_cols, q_stride, &d_q);
+    do {
+        if (rc != PN_OK) break;
+        if (hipMalloc((void **)&d_idx, nq * kout * sizeof(uint64_t)) != hipSuccess ||
+            hipMalloc((void **)&d_dist, nq * kout * sizeof(T)) != hipSuccess) {
+            rc = fail(PN_ERR_NOMEM, "hipMalloc results failed");
+            break;
+        }
+        rc = query_device_impl<T>(ix, d_q, nq, q_cols, q_cols ? q_cols : 1, k, d_idx, d_dist, ix->stream);
+        if (rc != PN_OK) break;
+        if (hipStreamSynchronize(ix->stream) != hipSuccess ||
+            hipMemcpy(idx_out, d_idx, nq * kout * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(dist_out, d_dist, nq * kout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (d_q) (void)hipFree(d_q);
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_dist) (void)hipFree(d_dist);
+    return rc;
+}
+
+extern "C" int pn_query_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, size_t k,
+                            uint64_t *idx_out, float *dist_out) {
+    return query_host_impl<float>(ix, q, nq, q_cols, q_stride, k, idx_out, dist_out);
+}
+extern "C" int pn_query_f64(const pn_index *ix, const double *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                            size_t k, uint64_t *idx_out, double *dist_out) {
+    return query_host_impl<double>(ix, q, nq, q_cols, q_stride, k, idx_out, dist_out);
+}
+extern "C" int pn_query_nearest_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                                    uint64_t *idx_out, float *dist_out) {
+    return query_host_impl<float>(ix, q, nq, q_cols, q_stride, 1, idx_out, dist_out);
+}
+extern "C" int pn_query_nearest_f64(const pn_index *ix, const double *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                                    uint64_t *idx_out, double *dist_out) {
+    return query_host_impl<double>(ix, q, nq, q_cols, q_stride, 1, idx_out, dist_out);
+}
+
+// ---------------------------------------------------------------------------
+// radius (two-pass CSR on the exact engine)
+// ---------------------------------------------------------------------------
+template <typename T> struct RadOps;
+template <> struct RadOps<float> {
+    static hipError_t run(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, float r,
+                          size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offs, uint64_t *fill,
+                          uint64_t base, hipStream_t s) {
+        return launch_exact_radius_f32(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, s);
+    }
+};
+template <> struct RadOps<double> {
+    static hipError_t run(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, double r,
+                          size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offs, uint64_t *fill,
+                          uint64_t base, hipStream_t s) {
+        return launch_exact_radius_f64(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, s);
+    }
+};
+
+template <typename T>
+static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, T radius,
+                            uint64_t *offsets, uint64_t **idx_out) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
+    if (!offsets || !idx_out) return fail(PN_ERR_INVALID, "output pointer is NULL");
+    *idx_out = nullptr;
+    offsets[0] = 0;
+    if (nq == 0) return PN_OK;
+    if (!q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
+    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    hipStream_t s = ix->stream;
+    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
+    const size_t nq_pad = round_up(nq, (size_t)kRowPad);
+    T *d_q = nullptr;
+    uint32_t *d_counts = nullptr;
+    uint64_t *d_offs = nullptr, *d_fill = nullptr;
+    int rc = upload_rows<T>(q, nq, q_cols, q_stride, &d_q);
+    std::vector<uint32_t> h_counts;
+    std::vector<uint64_t> h_offs;
+    do {
+        if (rc != PN_OK) break;
+        rc = ix->w_q.ensure(nq_pad * ix->ld * sizeof(T));
+        if (rc != PN_OK) break;
+        T *Qp = (T *)ix->w_q.p;
+        if (Ops<T>::pack(d_q, nq, dim_eff, q_cols ? q_cols : 1, Qp, nq_pad, ix->ld, s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "pack failed");
+            break;
+        }
+        const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, 1, ix->opt_segments, 4096, 64);
+        const size_t cells = nq * (size_t)pl.nseg;
+        if (hipMalloc((void **)&d_counts, cells * 4) != hipSuccess || hipMalloc((void **)&d_offs, cells * 8) != hipSuccess) {
+            rc = fail(PN_ERR_NOMEM, "hipMalloc radius scratch failed");
+            break;
+        }
+        if (hipMemsetAsync(d_counts, 0, cells * 4, s) != hipSuccess ||
+            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
+                           pl.nseg, d_counts, nullptr, nullptr, ix->index_base, s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius count pass failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        h_counts.resize(cells);
+        h_offs.resize(cells);
+        if (hipMemcpyAsync(h_counts.data(), d_counts, cells * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius count copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        uint64_t run = 0;
+        for (size_t a = 0; a < nq; ++a) {
+            offsets[a] = run;
+            for (int sg = 0; sg < pl.nseg; ++sg) {
+                h_offs[a * pl.nseg + sg] = run;
+                run += h_counts[a * pl.nseg + sg];
+            }
+        }
+        offsets[nq] = run;
+        ix->stats.radius_results += run;
+        uint64_t *h_out = (uint64_t *)malloc((run ? run : 1) * sizeof(uint64_t));
+        if (!h_out) { rc = fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)run); break; }
+        *idx_out = h_out;
+        if (run == 0) break;
+        if (hipMalloc((void **)&d_fill, run * 8) != hipSuccess) { rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed"); break; }
+        if (hipMemcpyAsync(d_offs, h_offs.data(), cells * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
+                           pl.nseg, d_counts, d_offs, d_fill, ix->index_base, s) != hipSuccess ||
+            hipMemcpyAsync(h_out, d_fill, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius fill pass failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (rc != PN_OK && *idx_out) { free(*idx_out); *idx_out = nullptr; }
+    if (d_q) (void)hipFree(d_q);
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_offs) (void)hipFree(d_offs);
+    if (d_fill) (void)hipFree(d_fill);
+    return rc;
+}
+
+extern "C" int pn_query_radius_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                                   float radius, uint64_t *offsets, uint64_t **idx_out) {
+    return radius_host_impl<float>(ix, q, nq, q_cols, q_stride, radius, offsets, idx_out);
+}
+extern "C" int pn_query_radius_f64(const pn_index *ix, const double *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                                   double radius, uint64_t *offsets, uint64_t **idx_out) {
+    return radius_host_impl<double>(ix, q, nq, q_cols, q_stride, radius, offsets, idx_out);
+}
+extern "C" void pn_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------------------
+// pairwise
+// ---------------------------------------------------------------------------
+template <typename T>
+static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, T *out) {
+    if (!out && n) return fail(PN_ERR_INVALID, "out is NULL");
+    if (n == 0) return PN_OK;
+    if (n < 2) {  // src/distance.rs:63-65
+        memset(out, 0, n * n * sizeof(T));
+        return PN_OK;
+    }
+    if (!x && cols) return fail(PN_ERR_INVALID, "x is NULL");
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    const size_t ld = round_up(cols ? cols : 1, kRowAlign), n_pad = round_up(n, (size_t)kRowPad);
+    T *d_x = nullptr, *d_p = nullptr, *d_o = nullptr;
+    int rc = upload_rows<T>(x, n, cols, row_stride, &d_x);
+    do {
+        if (rc != PN_OK) break;
+        if (hipMalloc((void **)&d_p, n_pad * ld * sizeof(T)) != hipSuccess ||
+            hipMalloc((void **)&d_o, n * n * sizeof(T)) != hipSuccess) {
+            rc = fail(PN_ERR_NOMEM, "hipMalloc pairwise failed");
+            break;
+        }
+        hipError_t e = Ops<T>::pack(d_x, n, cols, cols ? cols : 1, d_p, n_pad, ld, nullptr);
+        if (e == hipSuccess)
+            e = (sizeof(T) == 4) ? launch_exact_pairwise_f32((const float *)d_p, n, (int)cols, ld, (float *)d_o, nullptr)
+                                 : launch_exact_pairwise_f64((const double *)d_p, n, (int)cols, ld, (double *)d_o, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out, d_o, n * n * sizeof(T), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(PN_ERR_DEVICE, "pairwise: %s", hipGetErrorString(e));
+    } while (0);
+    if (d_x) (void)hipFree(d_x);
+    if (d_p) (void)hipFree(d_p);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
+}
+extern "C" int pn_pairwise_f32(const float *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, float *out) {
+    return pairwise_impl<float>(x, n, cols, row_stride, device, out);
+}
+extern "C" int pn_pairwise_f64(const double *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, double *out) {
+    return pairwise_impl<double>(x, n, cols, row_stride, device, out);
+}
+
+// ---------------------------------------------------------------------------
+// shard merge + generator
+// ---------------------------------------------------------------------------
+extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
+                                        size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
+                                        float *d_dist_out, int device, void *stream) {
+    if (nq == 0 || k_out == 0) return PN_OK;
+    if (!d_idx_parts || !d_dist_parts || !d_idx_out || !d_dist_out) return fail(PN_ERR_INVALID, "NULL argument");
+    if (n_parts == 0 || k_part == 0) return fail(PN_ERR_INVALID, "empty parts");
+    if (n_parts * k_part * 12 > 64 * 1024) return fail(PN_ERR_UNSUPPORTED, "n_parts * k_part too large for one merge");
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    HIPCHK(launch_merge_topk_f32(d_idx_parts, d_dist_parts, (int)n_parts, (int)nq, (int)k_part, (int)k_out, d_idx_out,
+                                 d_dist_out, (hipStream_t)stream));
+    return PN_OK;
+}
+
+extern "C" int pn_fill_uniform_device_f32(float *d_out, uint64_t count, uint64_t seed, uint64_t first_counter,
+                                          int device, void *stream) {
+    if (count == 0) return PN_OK;
+    if (!d_out) return fail(PN_ERR_INVALID, "d_out is NULL");
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    HIPCHK(launch_fill_uniform_f32(d_out, count, seed, first_counter, (hipStream_t)stream));
+    return PN_OK;
+}

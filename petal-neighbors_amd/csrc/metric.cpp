@@ -1,0 +1,31 @@
+// metric.cpp -- scalar Metric<A> for Euclidean (reference src/distance.rs:21-55).
+// Host-side BY DESIGN: the reference's Metric::distance is a one-pair scalar
+// call; the batched forms (query, pairwise) run on the GPU.  Sequential,
+// unfused fold + correctly rounded sqrt: bit-identical to the device kernels.
+// Built with -ffp-contract=off (and the pragma below) so no FMA can appear.
+#include <cmath>
+#include <cstddef>
+
+#include "../../include/petal_mi355x.h"
+
+#pragma STDC FP_CONTRACT OFF
+
+template <typename T>
+static inline T fold(const T *a, const T *b, size_t len) {
+    T sum = (T)0;
+    for (size_t i = 0; i < len; ++i) {
+        const T diff = a[i] - b[i];
+        const T sq = diff * diff;
+        sum = sum + sq;
+    }
+    return sum;
+}
+
+extern "C" float pn_reuclidean_f32(const float *a, const float *b, size_t len) { return fold<float>(a, b, len); }
+extern "C" double pn_reuclidean_f64(const double *a, const double *b, size_t len) { return fold<double>(a, b, len); }
+extern "C" float pn_euclidean_f32(const float *a, const float *b, size_t len) { return sqrtf(fold<float>(a, b, len)); }
+extern "C" double pn_euclidean_f64(const double *a, const double *b, size_t len) { return sqrt(fold<double>(a, b, len)); }
+extern "C" float pn_rdistance_to_distance_f32(float d) { return sqrtf(d); }    // src/distance.rs:47-49
+extern "C" double pn_rdistance_to_distance_f64(double d) { return sqrt(d); }
+extern "C" float pn_distance_to_rdistance_f32(float d) { return d * d; }       // powi(2), src/distance.rs:52-54
+extern "C" double pn_distance_to_rdistance_f64(double d) { return d * d; }

@@ -1,0 +1,111 @@
+// pn_internal.h -- shared declarations between the translation units of
+// libpetal_mi355x.so (gfx950 only).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace pn {
+
+// ---- tiling constants of the exact scan (exact_scan.hip)
+constexpr int kTileQ = 64;    // queries per workgroup tile
+constexpr int kTileP = 64;    // corpus rows per tile step
+constexpr int kChunkK = 32;   // coordinates staged per LDS chunk
+constexpr int kRowAlign = 8;  // device rows are zero-padded to a multiple of 8 elements
+constexpr int kRowPad = 256;  // device row COUNT is padded (zero rows) to a multiple of this
+
+// ---- sortable integer keys.  Distances are >= +0 or NaN, so the IEEE bit
+// pattern read as an unsigned integer is monotone; NaN is canonicalised to the
+// quiet-NaN pattern, which is greater than +inf: exactly ordered-float's total
+// order used by Neighbor (reference src/ball_tree.rs:396-421).
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+    using type = uint32_t;
+    static constexpr type kMax = 0xFFFFFFFFu;
+    static constexpr type kNaN = 0x7FC00000u;
+};
+template <> struct KeyOf<double> {
+    using type = uint64_t;
+    static constexpr type kMax = 0xFFFFFFFFFFFFFFFFull;
+    static constexpr type kNaN = 0x7FF8000000000000ull;
+};
+
+// Per-(segment, query) candidate buffers in HBM, filled by the scan kernels and
+// consumed by the select kernel.  Layout: [seg][query][slot].
+struct CandBuf {
+    void *keys;      // KeyOf<T>::type (exact) or float bits of the lower bound (MFMA filter)
+    uint32_t *idx;   // corpus row (local to this index)
+    uint32_t *cnt;   // entries in use            [seg][query]
+    void *tau;       // last threshold (same type as keys) [seg][query]
+    size_t nq_pad;   // queries padded to a multiple of kTileQ
+    int nseg;
+    int cap;         // slots per (segment, query); multiple of 64
+};
+
+inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- exact_scan.hip
+hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s);
+hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s);
+// radius: count pass (fill == nullptr) then fill pass.  counts/offsets are [query][seg].
+hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
+                                   size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base,
+                                   hipStream_t s);
+hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
+                                   size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base,
+                                   hipStream_t s);
+hipError_t launch_exact_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *out, hipStream_t s);
+hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *out, hipStream_t s);
+
+// ---- select.hip
+// Exact mode: keys are exact distance keys; picks the kout smallest (key, idx).
+hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                   float *dist_out, hipStream_t s);
+hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                   double *dist_out, hipStream_t s);
+// MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
+// in the reference's operation order, selects, and verifies the filter's
+// exclusions (flags[q] = 1 -> the query must be re-run exactly).
+hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
+                                    const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
+                                    uint64_t *idx_out, float *dist_out, uint32_t *flags,
+                                    uint32_t *n_flagged, uint64_t *n_cand, hipStream_t s);
+hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts, int nq,
+                                 int k_part, int k_out, uint64_t *idx_out, float *dist_out, hipStream_t s);
+// gather rows `sel[i]` of src into dst (row-padded), scatter results back
+hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, int nsel, float *dst,
+                                  hipStream_t s);
+hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel,
+                                      int nsel, int kout, uint64_t *idx_out, float *dist_out, hipStream_t s);
+hipError_t launch_compact_flags(const uint32_t *flags, int nq, uint32_t *sel, uint32_t *nsel, hipStream_t s);
+
+// ---- pack.hip
+// dst[r][c] = (r < n && c < cols) ? src[r*row_stride + c] : 0  for r < n_pad, c < ld
+hipError_t launch_pack_rows_f32(const float *src, size_t n, size_t cols, size_t row_stride, float *dst,
+                                size_t n_pad, size_t ld, hipStream_t s);
+hipError_t launch_pack_rows_f64(const double *src, size_t n, size_t cols, size_t row_stride, double *dst,
+                                size_t n_pad, size_t ld, hipStream_t s);
+hipError_t launch_fill_uniform_f32(float *out, uint64_t count, uint64_t seed, uint64_t first, hipStream_t s);
+// scaled squared row norms for the MFMA lower bound (see mfma_filter.hip)
+hipError_t launch_row_norms_f32(const float *X, size_t n_pad, size_t n, int dim, size_t ld, float alpha,
+                                float *norm_out, uint32_t *nonfinite_flag, hipStream_t s);
+
+// ---- mfma_filter.hip
+struct MfmaPlan {
+    int nseg;        // corpus segments per query tile
+    size_t seg_len;  // rows per segment (multiple of the kernel's row tile)
+    int kp;          // candidates kept per (segment, query)
+    int cap;         // slots per (segment, query)
+};
+bool mfma_supported(int dim, size_t ld);
+hipError_t launch_mfma_filter_f32(const float *P, const float *pnorm, size_t n, size_t n_pad, int dim,
+                                  size_t ldp, const float *Q, const float *qnorm, int nq, size_t ldq,
+                                  const MfmaPlan &plan, const CandBuf &cb, hipStream_t s);
+const char *mfma_kernel_name();
+
+}  // namespace pn

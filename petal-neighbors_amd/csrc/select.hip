@@ -1,0 +1,309 @@
+// select.hip -- final selection kernels (gfx950).
+//
+// After a scan kernel has left, per (segment, query), at most kp candidates in
+// HBM, one wave per query gathers them into LDS, ranks them by the total order
+// (distance key, index) -- Neighbor's order, reference src/ball_tree.rs:396-421,
+// with ascending index inside equal-distance groups -- and writes the first
+// kout.  In MFMA mode the candidates carry only a lower bound, so the kernel
+// first recomputes every candidate's distance in the reference's operation
+// order (src/distance.rs:26-35) and then PROVES that nothing the filter dropped
+// could belong to the answer; queries it cannot prove are flagged for the exact
+// engine.  Compiled with -ffp-contract=off.
+#include "pn_internal.h"
+
+namespace pn {
+
+__device__ __forceinline__ uint32_t sel_key(float d) { return (d != d) ? KeyOf<float>::kNaN : __float_as_uint(d); }
+__device__ __forceinline__ uint64_t sel_key(double d) {
+    return (d != d) ? KeyOf<double>::kNaN : (uint64_t)__double_as_longlong(d);
+}
+__device__ __forceinline__ float key_to_dist(uint32_t k) { return __uint_as_float(k); }
+__device__ __forceinline__ double key_to_dist(uint64_t k) { return __longlong_as_double((long long)k); }
+
+// rank of entry e among n LDS entries under (key, idx); one lane per entry
+template <typename KeyT, typename IdxT>
+__device__ __forceinline__ uint32_t rank_of(const KeyT *skey, const IdxT *sidx, uint32_t n, KeyT k, IdxT ix) {
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const KeyT bk = skey[j];
+        const IdxT bi = sidx[j];
+        r += ((bk < k) || (bk == k && bi < ix)) ? 1u : 0u;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// exact mode: block = 64 threads = one query
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T>::type *__restrict__ ckey,
+                                                          const uint32_t *__restrict__ cidx,
+                                                          const uint32_t *__restrict__ ccnt, size_t nq_pad, int nseg,
+                                                          int cap, int kout, uint64_t index_base,
+                                                          uint64_t *__restrict__ idx_out, T *__restrict__ dist_out) {
+    using KeyT = typename KeyOf<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    int total_cap = 0;
+    for (int s = 0; s < nseg; ++s) total_cap += (int)ccnt[(size_t)s * nq_pad + q];
+    KeyT *skey = reinterpret_cast<KeyT *>(smem);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(smem + sizeof(KeyT) * (size_t)total_cap);
+    uint32_t n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const uint32_t c = ccnt[(size_t)s * nq_pad + q];
+        const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
+        for (uint32_t e = lane; e < c; e += 64) {
+            skey[n + e] = ckey[base + e];
+            sidx[n + e] = cidx[base + e];
+        }
+        n += c;
+    }
+    __syncthreads();
+    for (uint32_t e = lane; e < n; e += 64) {
+        const KeyT k = skey[e];
+        const uint32_t ix = sidx[e];
+        const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
+        if (r < (uint32_t)kout) {
+            idx_out[q * kout + r] = index_base + ix;
+            dist_out[q * kout + r] = key_to_dist(k);
+        }
+    }
+    for (uint32_t r = n + lane; r < (uint32_t)kout; r += 64) {  // cannot happen for kout = min(k, n_points)
+        idx_out[q * kout + r] = ~0ull;
+        dist_out[q * kout + r] = key_to_dist(KeyOf<T>::kNaN);
+    }
+}
+
+template <typename T>
+static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                      T *dist_out, int kp_bound, hipStream_t s) {
+    using KeyT = typename KeyOf<T>::type;
+    const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq), dim3(64), sh, s,
+                       static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
+                       index_base, idx_out, dist_out);
+    return hipGetLastError();
+}
+hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                   float *dist_out, hipStream_t s) {
+    return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, s);
+}
+hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                   double *dist_out, hipStream_t s) {
+    return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, s);
+}
+
+// ---------------------------------------------------------------------------
+// MFMA mode: exact re-rank + verification.  block = 64 threads = one query.
+//
+// Candidates: per segment up to `cap` (idx, L) pairs with L <= d2(q, p) in real
+// arithmetic for every corpus row p (mfma_filter.hip proves this bound), and
+// tau_seg such that every row of the segment NOT in the buffer has L >= tau_seg
+// (tau_seg = +inf when nothing was ever dropped).
+//
+// Reference value: s_ref = fl-fold >= d2 * (1 - (D+3)u) - D*2^-149  (u = 2^-24):
+// three roundings per term, D additions, gradual underflow.  Distances are
+// f32 sqrt(s_ref), correctly rounded, hence monotone in s_ref.
+// A dropped row is provably outside the answer when
+//     tau_seg * (1 - (D+4)u) - 1e-37  >  ((d_k + succ(d_k)) / 2)^2
+// (everything at or below the right-hand side may still round to d_k and tie).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float exact_distance_f32(const float *__restrict__ q, const float *__restrict__ p,
+                                                    int dim) {
+#pragma clang fp contract(off)
+    float s = 0.0f;
+    int k = 0;
+    for (; k + 4 <= dim; k += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(q + k);
+        const float4 b = *reinterpret_cast<const float4 *>(p + k);
+        float d;
+        d = a.x - b.x; s = s + d * d;
+        d = a.y - b.y; s = s + d * d;
+        d = a.z - b.z; s = s + d * d;
+        d = a.w - b.w; s = s + d * d;
+    }
+    for (; k < dim; ++k) {
+        const float d = q[k] - p[k];
+        s = s + d * d;
+    }
+    return sqrtf(s);
+}
+
+__global__ __launch_bounds__(64) void select_rerank_kernel(
+    const float *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
+    size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
+    size_t ldq, int dim, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
+    float *__restrict__ dist_out, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
+    unsigned long long *__restrict__ n_cand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t kth_key;
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    int total_cap = 0;
+    float min_tau = __uint_as_float(0x7F800000u);  // +inf
+    for (int s = 0; s < nseg; ++s) {
+        total_cap += (int)ccnt[(size_t)s * nq_pad + q];
+        const float t = ctau[(size_t)s * nq_pad + q];
+        min_tau = (t < min_tau) ? t : min_tau;
+    }
+    uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *sidx = skey + total_cap;
+    if (lane == 0) kth_key = KeyOf<float>::kNaN;
+    const float *qrow = Q + q * ldq;
+    uint32_t n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const uint32_t c = ccnt[(size_t)s * nq_pad + q];
+        const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
+        for (uint32_t e = lane; e < c; e += 64) {
+            const uint32_t ix = cidx[base + e];
+            sidx[n + e] = ix;
+            skey[n + e] = sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim));
+        }
+        n += c;
+    }
+    __syncthreads();
+    for (uint32_t e = lane; e < n; e += 64) {
+        const uint32_t k = skey[e];
+        const uint32_t ix = sidx[e];
+        const uint32_t r = rank_of<uint32_t, uint32_t>(skey, sidx, n, k, ix);
+        if (r < (uint32_t)kout) {
+            idx_out[q * kout + r] = index_base + ix;
+            dist_out[q * kout + r] = key_to_dist(k);
+            if (r == (uint32_t)kout - 1) kth_key = k;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        bool ok = n >= (uint32_t)kout;
+        const uint32_t kk = kth_key;
+        if (ok && kk >= 0x7F800000u) ok = false;  // k-th distance is inf/NaN: let the exact engine order it
+        if (ok && min_tau < __uint_as_float(0x7F800000u)) {
+            const double dk = (double)__uint_as_float(kk);
+            const double dn = (double)__uint_as_float(kk + 1);  // succ(d_k): next float up (d_k finite, >= +0)
+            const double mid = 0.5 * (dk + dn);
+            const double rhs = mid * mid * (1.0 + 4.5e-16);
+            const double u = 5.9604644775390625e-08;  // 2^-24
+            const double lb = (double)min_tau * (1.0 - (double)(dim + 4) * u) - 1e-37;
+            ok = (min_tau == min_tau) && (lb > rhs);
+        }
+        flags[q] = ok ? 0u : 1u;
+        if (!ok) atomicAdd(n_flagged, 1u);
+        atomicAdd(n_cand, (unsigned long long)n);
+    }
+}
+
+hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
+                                    const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
+                                    uint64_t *idx_out, float *dist_out, uint32_t *flags, uint32_t *n_flagged,
+                                    uint64_t *n_cand, hipStream_t s) {
+    (void)n;
+    const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 8;
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
+                       static_cast<const float *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
+                       ldq, dim, kout, index_base, idx_out, dist_out, flags, n_flagged,
+                       reinterpret_cast<unsigned long long *>(n_cand));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// shard merge: parts laid out [part][query][k_part]; (dist, idx) total order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restrict__ idx_parts,
+                                                        const float *__restrict__ dist_parts, int n_parts, int nq,
+                                                        int k_part, int k_out, uint64_t *__restrict__ idx_out,
+                                                        float *__restrict__ dist_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
+    uint64_t *sidx = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
+    for (uint32_t e = lane; e < n; e += 64) {
+        const uint32_t part = e / k_part, j = e % k_part;
+        const size_t o = ((size_t)part * nq + q) * k_part + j;
+        const uint64_t ix = idx_parts[o];
+        sidx[e] = ix;
+        skey[e] = (ix == ~0ull) ? KeyOf<float>::kMax : sel_key(dist_parts[o]);
+    }
+    __syncthreads();
+    uint32_t n_valid = 0;
+    for (uint32_t e = lane; e < n; e += 64) {
+        const uint32_t k = skey[e];
+        const uint64_t ix = sidx[e];
+        if (k == KeyOf<float>::kMax) continue;
+        const uint32_t r = rank_of<uint32_t, uint64_t>(skey, sidx, n, k, ix);
+        if (r < (uint32_t)k_out) {
+            idx_out[q * k_out + r] = ix;
+            dist_out[q * k_out + r] = key_to_dist(k);
+        }
+    }
+    // absent tail (fewer than k_out valid entries over all parts)
+    for (uint32_t e = lane; e < n; e += 64) n_valid += skey[e] != KeyOf<float>::kMax;
+    for (int d = 32; d > 0; d >>= 1) n_valid += __shfl_xor(n_valid, d);
+    for (uint32_t r = n_valid + lane; r < (uint32_t)k_out; r += 64) {
+        idx_out[q * k_out + r] = ~0ull;
+        dist_out[q * k_out + r] = key_to_dist(KeyOf<float>::kNaN);
+    }
+}
+
+hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts, int nq,
+                                 int k_part, int k_out, uint64_t *idx_out, float *dist_out, hipStream_t s) {
+    const size_t sh = (size_t)n_parts * k_part * 12;
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts, nq,
+                       k_part, k_out, idx_out, dist_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// fallback plumbing: list flagged queries, gather their rows, scatter results
+// ---------------------------------------------------------------------------
+__global__ void compact_flags_kernel(const uint32_t *__restrict__ flags, int nq, uint32_t *__restrict__ sel,
+                                     uint32_t *__restrict__ nsel) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq && flags[q]) sel[atomicAdd(nsel, 1u)] = (uint32_t)q;
+}
+hipError_t launch_compact_flags(const uint32_t *flags, int nq, uint32_t *sel, uint32_t *nsel, hipStream_t s) {
+    hipLaunchKernelGGL(compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, flags, nq, sel,
+                       nsel);
+    return hipGetLastError();
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, size_t ld, const uint32_t *__restrict__ sel,
+                                   int nsel, float *__restrict__ dst) {
+    const size_t i = blockIdx.x;
+    if (i >= (size_t)nsel) return;
+    const float *s = src + (size_t)sel[i] * ld;
+    float *d = dst + i * ld;
+    for (size_t c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
+}
+hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, int nsel, float *dst,
+                                  hipStream_t s) {
+    if (nsel == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nsel), dim3(64), 0, s, src, ld, sel, nsel, dst);
+    return hipGetLastError();
+}
+
+__global__ void scatter_results_kernel(const uint64_t *__restrict__ idx_in, const float *__restrict__ dist_in,
+                                       const uint32_t *__restrict__ sel, int nsel, int kout,
+                                       uint64_t *__restrict__ idx_out, float *__restrict__ dist_out) {
+    const size_t i = blockIdx.x;
+    if (i >= (size_t)nsel) return;
+    const size_t q = sel[i];
+    for (int j = threadIdx.x; j < kout; j += blockDim.x) {
+        idx_out[q * kout + j] = idx_in[i * kout + j];
+        dist_out[q * kout + j] = dist_in[i * kout + j];
+    }
+}
+hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel, int nsel,
+                                      int kout, uint64_t *idx_out, float *dist_out, hipStream_t s) {
+    if (nsel == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)nsel), dim3(64), 0, s, idx_in, dist_in, sel, nsel,
+                       kout, idx_out, dist_out);
+    return hipGetLastError();
+}
+
+}  // namespace pn

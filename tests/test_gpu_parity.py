@@ -1,0 +1,288 @@
+"""Parity tests proper (need an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the reference's golden
+vectors, and -- at BASELINE sizes -- through size-independent properties.
+
+Bar: indices and distances BIT-EXACT (distances compared as raw bytes); inside
+groups of exactly equal distances the reference's index order is unspecified
+(SURVEY.md A.3), this library returns ascending index = the oracle's canonical
+brute force, so the comparison is still exact equality.
+"""
+import numpy as np
+import pytest
+
+from conftest import uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_bits(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def _same_dist(a, b):
+    """bit-exact, with NaN == NaN regardless of payload"""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    return a[~na].tobytes() == b[~nb].tobytes()
+
+
+def _check_knn(pn, oracle_mod, pts, qs, k, engine="exact", **opts):
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine(engine)
+    for o, v in opts.items():
+        tree.set_option(o, v)
+    idx, dist = tree.query_batch(qs, k)
+    oidx, odist = oracle_mod.brute_knn(pts, qs, k)
+    assert _same_dist(dist, odist), f"distances differ (engine={engine})"
+    assert np.array_equal(idx, oidx), f"indices differ (engine={engine})"
+    return tree
+
+
+# --------------------------------------------------------------- golden vectors
+def test_reference_golden_vectors_on_gpu(pn, kats):
+    """Every k-NN / nearest / radius / pairwise vector of the reference's tests, f64, on the GPU."""
+    n_ops = 0
+    for v in kats["vectors"]:
+        if "shape" in v or v.get("fortran") or not v["points"]:
+            continue
+        pts = np.array(v["points"], dtype=np.float64)
+        tree = None
+        for op in v["ops"]:
+            kind = op["op"]
+            where = f'{v["id"]} {kind}'
+            if kind == "pairwise":
+                got = pn.distance.pairwise(pts, pn.distance.Euclidean())
+                assert np.array_equal(got, np.array(op["expect"])), where
+                n_ops += 1
+                continue
+            if kind not in ("query", "query_nearest", "query_radius"):
+                continue
+            if tree is None:
+                tree = pn.BallTree.euclidean(pts)
+            q = np.array(op["point"], dtype=np.float64)
+            n_ops += 1
+            if kind == "query":
+                idx, dist = tree.query(q, op["k"])
+                if "expect_idx" in op:
+                    assert list(idx) == op["expect_idx"], where
+                if "expect_dist" in op:
+                    assert len(dist) == len(op["expect_dist"]), where
+                    for a, b in zip(dist, op["expect_dist"]):
+                        assert abs(a - b) <= op["tol"], where
+            elif kind == "query_nearest":
+                i, d = tree.query_nearest(q)
+                if "expect_idx" in op:
+                    assert i == op["expect_idx"], where
+                if "expect_dist" in op:
+                    assert abs(d - op["expect_dist"]) <= op["tol"], where
+            else:
+                got = sorted(int(x) for x in tree.query_radius(q, op["r"]))
+                assert got == op["expect_sorted"], where
+    assert n_ops >= 20
+
+
+def test_reference_property_test_on_gpu(pn, oracle_mod, kats):
+    """ball_tree_query (src/ball_tree.rs:742-765): 40x3 f64, 10 queries, k=5 == naive scan."""
+    pt = kats["property_test"]
+    rng = np.random.default_rng(7)
+    pts = rng.random((pt["n"], pt["dim"]))
+    qs = rng.random((pt["queries"], pt["dim"]))
+    _check_knn(pn, oracle_mod, pts, qs, pt["k"])
+
+
+# ------------------------------------------------------------- exact engine
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,dim,nq,k", [
+    (1, 1, 3, 1), (3, 2, 5, 2), (64, 10, 64, 5), (128, 10, 16, 5), (1000, 3, 50, 2),   # bench shapes
+    (257, 7, 33, 10), (4097, 33, 70, 17), (5000, 128, 130, 10), (3000, 96, 9, 100),
+    (2000, 131, 20, 64), (900, 16, 11, 65), (1500, 8, 7, 200), (70, 5, 4, 1000),
+])
+def test_exact_engine_vs_oracle(pn, oracle_mod, dtype, n, dim, nq, k):
+    pts = uniform((n, dim), 0x5EED0001 + n + dim, dtype)
+    qs = uniform((nq, dim), 0x5EED0002 + n + dim, dtype)
+    _check_knn(pn, oracle_mod, pts, qs, k)
+
+
+def test_exact_engine_signed_wide_range(pn, oracle_mod):
+    rng = np.random.default_rng(3)
+    pts = (rng.standard_normal((3000, 20)) * np.exp(rng.uniform(-6, 6, (3000, 1)))).astype(np.float32)
+    qs = (rng.standard_normal((40, 20)) * 3).astype(np.float32)
+    _check_knn(pn, oracle_mod, pts, qs, 12)
+
+
+@pytest.mark.parametrize("segments", [1, 2, 7])
+def test_segment_count_does_not_change_results(pn, oracle_mod, segments):
+    from petal_neighbors_amd import _lib
+    pts = uniform((9000, 24), 5, np.float32)
+    qs = uniform((77, 24), 6, np.float32)
+    _check_knn(pn, oracle_mod, pts, qs, 10, "exact", **{_lib.PN_OPT_SEGMENTS: segments})
+
+
+def test_ties_identical_points_and_grids(pn, oracle_mod):
+    """ball_tree_identical_points (src/ball_tree.rs:718-740) and heavy exact ties."""
+    pts = np.ones((8, 2))
+    tree = pn.BallTree.new(pts, pn.distance.Euclidean())
+    i, d = tree.query_nearest(np.array([1.0, 2.0]))
+    assert d == 1.0 and i == 0
+    i, d = tree.query_nearest(np.array([1.0, 1.0]))
+    assert d == 0.0 and i == 0
+    idx, dist = tree.query(np.array([1.0, 2.0]), 3)
+    assert list(idx) == [0, 1, 2] and list(dist) == [1.0, 1.0, 1.0]
+    # integer grid: thousands of exactly tied distances, k straddling tie groups
+    g = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0), np.arange(10.0), indexing="ij"), -1).reshape(-1, 3)
+    g = np.concatenate([g, g[:700]]).astype(np.float32)  # duplicates too
+    qs = np.array([[3.0, 3.0, 3.0], [0.5, 0.5, 0.5], [19.0, 19.0, 9.0], [7.25, 3.0, 1.0]], dtype=np.float32)
+    for k in (1, 7, 27, 100, 300):
+        _check_knn(pn, oracle_mod, g, qs, k)
+    same = np.full((5000, 6), 0.25, dtype=np.float32)
+    _check_knn(pn, oracle_mod, same, same[:3] + 1, 70)
+
+
+def test_nan_inf_and_k_edges(pn, oracle_mod):
+    """CHANGELOG.md:113-116: NaN never panics and sorts last; k=0 empty; k>n returns n."""
+    pts = uniform((300, 5), 9, np.float32)
+    pts[7, 2] = np.nan
+    pts[100, 0] = np.inf
+    pts[200, 4] = -np.inf
+    qs = uniform((6, 5), 10, np.float32)
+    qs[3, 1] = np.nan
+    tree = pn.BallTree.euclidean(pts)
+    idx, dist = tree.query_batch(qs, 300)
+    oidx, odist = oracle_mod.brute_knn(pts, qs, 300)
+    assert _same_dist(dist, odist) and np.array_equal(idx, oidx)
+    assert np.isnan(dist[0, -1]) and idx[0, -1] == 7 and np.isinf(dist[0, -2])
+    i0, d0 = tree.query(qs[0], 0)
+    assert len(i0) == 0 and len(d0) == 0
+    i5, d5 = tree.query(qs[0], 5000)
+    assert len(i5) == 300
+    for k in (1, 10):
+        idx, dist = tree.query_batch(qs, k)
+        oidx, odist = oracle_mod.brute_knn(pts, qs, k)
+        assert _same_dist(dist, odist) and np.array_equal(idx, oidx)
+
+
+def test_zip_truncation_and_strided_input(pn, oracle_mod):
+    """A query shorter/longer than D is silently truncated (src/distance.rs:27-28)."""
+    pts = uniform((500, 12), 21, np.float64)
+    tree = pn.BallTree.euclidean(pts)
+    q = uniform((12,), 22, np.float64)
+    idx, dist = tree.query(q[:5], 4)
+    oidx, odist = oracle_mod.brute_knn(pts[:, :5], q[:5], 4)
+    assert _eq_bits(dist, odist[0]) and np.array_equal(idx, oidx[0])
+    idx, dist = tree.query(np.concatenate([q, [9.0, 9.0]]), 4)
+    oidx, odist = oracle_mod.brute_knn(pts, q, 4)
+    assert _eq_bits(dist, odist[0]) and np.array_equal(idx, oidx[0])
+    # row stride > ncols is fine (only the inner stride is checked, src/ball_tree.rs:47)
+    wide = uniform((400, 16), 23, np.float32)
+    view = wide[:, :10]
+    t2 = pn.BallTree.euclidean(view)
+    idx, dist = t2.query_batch(wide[:9, :10], 3)
+    oidx, odist = oracle_mod.brute_knn(np.ascontiguousarray(view), np.ascontiguousarray(wide[:9, :10]), 3)
+    assert _eq_bits(dist, odist) and np.array_equal(idx, oidx)
+
+
+def test_sqrt_is_correctly_rounded_on_device(pn):
+    """1-D corpus: distance = sqrt(x^2 rounded) -- compare the device sqrt with IEEE host sqrt."""
+    rng = np.random.default_rng(5)
+    x = np.exp(rng.uniform(-40, 40, 20000)).astype(np.float32)
+    x[:4] = [0.0, 1e-45, 3.4e38, 1.1754944e-38]
+    pts = x.reshape(-1, 1)
+    tree = pn.BallTree.euclidean(pts)
+    idx, dist = tree.query_batch(np.zeros((1, 1), dtype=np.float32), len(x))
+    with np.errstate(over="ignore", under="ignore"):
+        want = np.sqrt((x * x).astype(np.float32))
+    got = np.empty_like(want)
+    got[idx[0].astype(np.int64)] = dist[0]
+    assert _same_dist(got, want)
+    # two-term sums exercise odd mantissas
+    y = rng.uniform(0, 1, (20000, 2)).astype(np.float32)
+    t2 = pn.BallTree.euclidean(y)
+    idx, dist = t2.query_batch(np.zeros((1, 2), dtype=np.float32), len(y))
+    s = (y[:, 0] * y[:, 0]).astype(np.float32) + (y[:, 1] * y[:, 1]).astype(np.float32)
+    want = np.sqrt(s.astype(np.float32))
+    got = np.empty_like(want)
+    got[idx[0].astype(np.int64)] = dist[0]
+    assert _eq_bits(got, want)
+
+
+# --------------------------------------------------------------- radius / pairwise
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_query_radius_vs_oracle(pn, oracle_mod, dtype):
+    """64x10 r=0.2 is the reference bench shape (benches/ball_tree.rs:22-41)."""
+    for n, dim, r in ((64, 10, 0.2), (64, 10, 0.9), (3000, 3, 0.15), (5000, 16, 1.2), (700, 128, 4.2)):
+        pts = uniform((n, dim), 31 + n, dtype)
+        qs = np.concatenate([pts[:20], uniform((13, dim), 32 + n, dtype)])
+        tree = pn.BallTree.euclidean(pts)
+        off, idx = tree.query_radius_batch(qs, r)
+        assert off[0] == 0 and off[-1] == len(idx)
+        tot = 0
+        for a in range(len(qs)):
+            want = oracle_mod.brute_radius(pts, qs[a], dtype(r))
+            got = idx[int(off[a]):int(off[a + 1])]
+            assert np.array_equal(got, want), (n, dim, r, a)
+            tot += len(want)
+        assert tot == len(idx)
+        one = tree.query_radius(qs[0], r)
+        assert np.array_equal(one, oracle_mod.brute_radius(pts, qs[0], dtype(r)))
+    # boundary: a point at distance exactly r is excluded (strict '<', src/ball_tree.rs:277)
+    line = np.array([[0.0], [2.0], [3.0], [4.0]], dtype=dtype)
+    t = pn.BallTree.euclidean(line)
+    assert list(t.query_radius(np.array([3.0], dtype=dtype), 1.0)) == [2]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pairwise_vs_oracle(pn, oracle_mod, dtype):
+    for n, dim in ((1, 3), (2, 2), (65, 7), (300, 128), (130, 131)):
+        x = uniform((n, dim), 41 + n, dtype)
+        got = pn.distance.pairwise(x, pn.distance.Euclidean())
+        want = oracle_mod.pairwise(x)
+        assert _eq_bits(got, want), (n, dim)
+        assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0)
+
+
+# --------------------------------------------------------- full-size properties
+def test_full_size_headline_properties(pn, oracle_mod):
+    """BASELINE.json configs[1]: 1M x 128 f32, k=10 (2 048 of the 10 000 queries to bound time).
+    Properties that need no full oracle: ascending distances; every returned distance equals the
+    scalar metric recomputed for its index (bit-exact); no duplicates; a sample of queries equals
+    the CPU oracle's brute force; both engines agree bit for bit."""
+    import torch
+    from petal_neighbors_amd import _lib
+    n, dim, nq, k = 1_000_000, 128, 2048, 10
+    L = _lib.lib()
+    pts_t = torch.empty((n, dim), dtype=torch.float32, device="cuda:0")
+    qs_t = torch.empty((nq, dim), dtype=torch.float32, device="cuda:0")
+    assert L.pn_fill_uniform_device_f32(pts_t.data_ptr(), n * dim, 0x5EED0001, 0, 0, None) == 0
+    assert L.pn_fill_uniform_device_f32(qs_t.data_ptr(), nq * dim, 0x5EED0002, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    tree = pn.BallTree.from_device(pts_t)
+    results = {}
+    engines = ["exact"] + (["mfma"] if tree.mfma_eligible else [])
+    for eng in engines:
+        tree.set_engine(eng)
+        i, d = tree.query_device(qs_t, k)
+        torch.cuda.synchronize()
+        results[eng] = (i.cpu().numpy().astype(np.uint64), d.cpu().numpy())
+    idx, dist = results["exact"]
+    for eng in engines[1:]:
+        assert np.array_equal(results[eng][0], idx) and _eq_bits(results[eng][1], dist), eng
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    assert all(len(set(r.tolist())) == k for r in idx[:256])
+    # device generator == oracle generator, bit for bit
+    head = oracle_mod.fill_uniform(1000 * dim, 0x5EED0001).reshape(1000, dim)
+    assert _eq_bits(pts_t[:1000].cpu().numpy(), head)
+    pts = pts_t.cpu().numpy()
+    qs = qs_t.cpu().numpy()
+    m = pn.distance.Euclidean()
+    for a in range(0, nq, 97):
+        for j in range(k):
+            assert m.distance(qs[a], pts[int(idx[a, j])]).tobytes() == dist[a, j].tobytes()
+    sample = list(range(0, nq, 128))
+    oidx, odist = oracle_mod.brute_knn(pts, qs[sample], k)
+    assert np.array_equal(idx[sample], oidx) and _eq_bits(dist[sample], odist)
