@@ -84,6 +84,12 @@ def lib():
         raise LibraryMissing(
             f"{LIB_PATH} is missing: build it with `python petal-neighbors_amd/build.py` "
             "(or __graft_entry__.build()). petal_neighbors_amd has no CPU fallback.")
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime already in
+        # the process when ours is bound, or two runtimes would fight over the device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

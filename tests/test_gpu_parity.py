@@ -32,10 +32,10 @@ def _same_dist(a, b):
     return a[~na].tobytes() == b[~nb].tobytes()
 
 
-def _check_knn(pn, oracle_mod, pts, qs, k, engine="exact", **opts):
+def _check_knn(pn, oracle_mod, pts, qs, k, engine="exact", opts=None):
     tree = pn.BallTree.euclidean(pts)
     tree.set_engine(engine)
-    for o, v in opts.items():
+    for o, v in (opts or {}).items():
         tree.set_option(o, v)
     idx, dist = tree.query_batch(qs, k)
     oidx, odist = oracle_mod.brute_knn(pts, qs, k)
@@ -121,7 +121,7 @@ def test_segment_count_does_not_change_results(pn, oracle_mod, segments):
     from petal_neighbors_amd import _lib
     pts = uniform((9000, 24), 5, np.float32)
     qs = uniform((77, 24), 6, np.float32)
-    _check_knn(pn, oracle_mod, pts, qs, 10, "exact", **{_lib.PN_OPT_SEGMENTS: segments})
+    _check_knn(pn, oracle_mod, pts, qs, 10, "exact", {_lib.PN_OPT_SEGMENTS: segments})
 
 
 def test_ties_identical_points_and_grids(pn, oracle_mod):
