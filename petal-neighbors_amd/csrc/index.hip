@@ -140,6 +140,14 @@ static int check_device(int device) {
     return PN_OK;
 }
 
+static size_t pick_ld(size_t dim) {
+    // D <= 128: one of the row lengths the MFMA filter is instantiated for; else a multiple of 8
+    const size_t set[] = {8, 16, 32, 64, 96, 128};
+    for (size_t v : set)
+        if (dim <= v) return v;
+    return round_up(dim, kRowAlign);
+}
+
 static float mfma_alpha(size_t dim) {
     // (2(D+2)+8) * 2^-24: covers the (D+2)-step MFMA fma chain twice (see mfma_filter.hip)
     return (float)((2.0 * (double)(dim + 2) + 8.0) * 5.9604644775390625e-08);
@@ -204,7 +212,7 @@ static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdi
     ix->elem_bytes = (int)sizeof(T);
     ix->n = n_rows;
     ix->dim = n_cols;
-    ix->ld = round_up(n_cols ? n_cols : 1, kRowAlign);
+    ix->ld = pick_ld(n_cols);
     ix->n_pad = round_up(n_rows, kRowPad);
     int rc = PN_OK;
     T *d_tmp = nullptr;
@@ -260,7 +268,7 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
     ix->elem_bytes = 4;
     ix->n = n_rows;
     ix->dim = n_cols;
-    ix->ld = round_up(n_cols ? n_cols : 1, kRowAlign);
+    ix->ld = pick_ld(n_cols);
     ix->n_pad = round_up(n_rows, kRowPad);
     int rc = PN_OK;
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess)
@@ -355,15 +363,16 @@ struct ScanPlan {
     size_t seg_len;
 };
 
-static ScanPlan plan_segments(size_t n, size_t q_tiles, int cap, int forced, size_t min_seg_rows, size_t max_entries) {
+static ScanPlan plan_segments(size_t n, size_t q_tiles, int cap, int forced, size_t min_seg_rows, size_t max_entries,
+                              size_t target_wgs = 2048, bool round_down = false) {
     size_t max_seg = max_entries / (size_t)cap;  // select kernel LDS budget
     if (max_seg < 1) max_seg = 1;
     size_t nseg;
     if (forced > 0) {
         nseg = (size_t)forced;
     } else {
-        const size_t target_wgs = 2048;
-        nseg = (target_wgs + q_tiles - 1) / q_tiles;
+        nseg = round_down ? target_wgs / q_tiles : (target_wgs + q_tiles - 1) / q_tiles;
+        if (nseg < 1) nseg = 1;
         const size_t by_rows = (n + min_seg_rows - 1) / min_seg_rows;
         if (nseg > by_rows) nseg = by_rows;
     }
@@ -450,6 +459,10 @@ static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, 
 
 static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
                     float *d_dist, hipStream_t s);
+static size_t mfma_slots(const pn_index *ix, size_t kout) {
+    size_t kp = ix->filter_slots > 0 ? (size_t)ix->filter_slots : kout + (kout < 16 ? 6 : kout / 4 + 4);
+    return kp < kout ? kout : kp;
+}
 
 template <typename T>
 static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
@@ -481,8 +494,8 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
         T *od = d_dist + qs * kout;
         bool use_mfma = false;
         if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
-            // the filter keeps kout + margin candidates per (segment, query) in at most 960 slots
-            use_mfma = kout <= 896;
+            // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
+            use_mfma = mfma_slots(ix, kout) + 64 <= 256;
             if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
         }
         if (use_mfma)
@@ -505,8 +518,7 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
 static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
                     float *d_dist, hipStream_t s) {
     // candidate slots kept per (segment, query)
-    size_t kp = ix->filter_slots > 0 ? (size_t)ix->filter_slots : kout + (kout < 16 ? 6 : kout / 4 + 4);
-    if (kp < kout) kp = kout;
+    const size_t kp = mfma_slots(ix, kout);
     int cap = pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
     // scaled query norms (same kernel as the corpus norms)
@@ -518,7 +530,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
     HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
                                 d_nflag + 1, s));
-    const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192);
+    const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192, 512, true);
     MfmaPlan plan{sp.nseg, sp.seg_len, (int)kp, cap};
     const size_t slots = (size_t)plan.nseg * nq_pad * (size_t)cap;
     PNCHK(ix->w_keys.ensure(slots * sizeof(uint32_t)));
@@ -773,7 +785,7 @@ static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride
     PNCHK(check_device(device));
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
-    const size_t ld = round_up(cols ? cols : 1, kRowAlign), n_pad = round_up(n, (size_t)kRowPad);
+    const size_t ld = pick_ld(cols), n_pad = round_up(n, (size_t)kRowPad);
     T *d_x = nullptr, *d_p = nullptr, *d_o = nullptr;
     int rc = upload_rows<T>(x, n, cols, row_stride, &d_x);
     do {

@@ -132,7 +132,7 @@ __device__ __forceinline__ float exact_distance_f32(const float *__restrict__ q,
 }
 
 __global__ __launch_bounds__(64) void select_rerank_kernel(
-    const float *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
+    const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
     size_t ldq, int dim, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
     float *__restrict__ dist_out, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
@@ -142,12 +142,13 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
     int total_cap = 0;
-    float min_tau = __uint_as_float(0x7F800000u);  // +inf
+    uint32_t min_key = 0xFF800000u;  // sortable(+inf): nothing dropped
     for (int s = 0; s < nseg; ++s) {
         total_cap += (int)ccnt[(size_t)s * nq_pad + q];
-        const float t = ctau[(size_t)s * nq_pad + q];
-        min_tau = (t < min_tau) ? t : min_tau;
+        const uint32_t t = ctau[(size_t)s * nq_pad + q];  // order-preserving keys (topk_buffer.h f2s)
+        min_key = (t < min_key) ? t : min_key;
     }
+    const float min_tau = __uint_as_float((min_key & 0x80000000u) ? (min_key & 0x7FFFFFFFu) : ~min_key);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sidx = skey + total_cap;
     if (lane == 0) kth_key = KeyOf<float>::kNaN;
@@ -202,7 +203,7 @@ hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n,
     const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 8;
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
-                       static_cast<const float *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
+                       static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
                        ldq, dim, kout, index_base, idx_out, dist_out, flags, n_flagged,
                        reinterpret_cast<unsigned long long *>(n_cand));
     return hipGetLastError();

@@ -192,23 +192,96 @@ def test_sqrt_is_correctly_rounded_on_device(pn):
     rng = np.random.default_rng(5)
     x = np.exp(rng.uniform(-40, 40, 20000)).astype(np.float32)
     x[:4] = [0.0, 1e-45, 3.4e38, 1.1754944e-38]
-    pts = x.reshape(-1, 1)
-    tree = pn.BallTree.euclidean(pts)
-    idx, dist = tree.query_batch(np.zeros((1, 1), dtype=np.float32), len(x))
     with np.errstate(over="ignore", under="ignore"):
         want = np.sqrt((x * x).astype(np.float32))
-    got = np.empty_like(want)
-    got[idx[0].astype(np.int64)] = dist[0]
-    assert _same_dist(got, want)
+    # pairwise against the origin: one row of the matrix holds sqrt(x_i^2) for every i
+    for lo in range(0, len(x), 1000):
+        blk = np.concatenate([np.zeros(1, dtype=np.float32), x[lo:lo + 1000]]).reshape(-1, 1)
+        got = pn.distance.pairwise(blk)[0, 1:]
+        assert _same_dist(got, want[lo:lo + 1000])
     # two-term sums exercise odd mantissas
-    y = rng.uniform(0, 1, (20000, 2)).astype(np.float32)
-    t2 = pn.BallTree.euclidean(y)
-    idx, dist = t2.query_batch(np.zeros((1, 2), dtype=np.float32), len(y))
+    y = rng.uniform(0, 1, (2000, 2)).astype(np.float32)
+    blk = np.concatenate([np.zeros((1, 2), dtype=np.float32), y])
+    got = pn.distance.pairwise(blk)[0, 1:]
     s = (y[:, 0] * y[:, 0]).astype(np.float32) + (y[:, 1] * y[:, 1]).astype(np.float32)
-    want = np.sqrt(s.astype(np.float32))
-    got = np.empty_like(want)
-    got[idx[0].astype(np.int64)] = dist[0]
-    assert _eq_bits(got, want)
+    assert _eq_bits(got, np.sqrt(s.astype(np.float32)))
+
+
+# ------------------------------------------------------------- MFMA filter engine
+@pytest.mark.parametrize("n,dim,nq,k", [
+    (5000, 128, 300, 10), (20000, 128, 130, 10), (7001, 96, 257, 10), (4100, 64, 64, 1),
+    (9000, 33, 100, 5), (3000, 8, 50, 10), (2500, 3, 40, 2), (6000, 1, 30, 7),
+    (12000, 128, 40, 100), (5000, 100, 33, 64), (70000, 16, 200, 10),
+])
+def test_mfma_engine_vs_oracle(pn, oracle_mod, n, dim, nq, k):
+    """MFMA filter + exact re-rank + verification == canonical brute force, bit for bit.
+    Queries mix corpus rows (distance 0: worst cancellation for the GEMM expansion) and fresh draws."""
+    pts = uniform((n, dim), 0xA11CE + n + dim, np.float32)
+    qs = np.concatenate([pts[: nq // 3], uniform((nq - nq // 3, dim), 0xB0B + n, np.float32)])
+    tree = _check_knn(pn, oracle_mod, pts, qs, k, "mfma")
+    st = tree.stats()
+    assert st["hot_launches"] == 0 and st["queries"] == nq
+    assert st["candidates"] >= nq * min(k, n)
+
+
+def test_mfma_engine_gaussian_clusters_and_scales(pn, oracle_mod):
+    rng = np.random.default_rng(11)
+    centers = rng.standard_normal((20, 48)) * 10
+    pts = (centers[rng.integers(0, 20, 30000)] + rng.standard_normal((30000, 48)) * 0.05).astype(np.float32)
+    qs = np.concatenate([pts[:64], (centers + 0.01).astype(np.float32)])
+    _check_knn(pn, oracle_mod, pts, qs, 10, "mfma")
+    big = (uniform((8000, 64), 77, np.float32) * 1e4 - 5e3).astype(np.float32)
+    _check_knn(pn, oracle_mod, big, big[:50] + np.float32(0.25), 10, "mfma")
+    tiny = (uniform((8000, 64), 78, np.float32) * 1e-20).astype(np.float32)
+    _check_knn(pn, oracle_mod, tiny, tiny[:50], 10, "mfma")
+
+
+def test_mfma_engine_falls_back_on_unprovable_queries(pn, oracle_mod):
+    """Heavy exact ties defeat the filter's proof (more tied rows than candidate slots): those
+    queries must be flagged and re-run on the exact engine -- results stay bit-exact."""
+    g = np.stack(np.meshgrid(np.arange(16.0), np.arange(16.0), np.arange(16.0), np.arange(4.0), indexing="ij"),
+                 -1).reshape(-1, 4).astype(np.float32)
+    g = np.concatenate([g, g, g])  # every row three times
+    qs = np.array([[3, 3, 3, 1], [0.5, 0.5, 0.5, 0.5], [15, 15, 15, 3], [7.25, 3, 1, 2]], dtype=np.float32)
+    tree = _check_knn(pn, oracle_mod, g, qs, 10, "mfma")
+    assert tree.stats()["fallback_queries"] >= 1
+    same = np.full((6000, 32), 0.25, dtype=np.float32)
+    tree = _check_knn(pn, oracle_mod, same, same[:5] + 1, 20, "mfma")
+    assert tree.stats()["fallback_queries"] == 5
+
+
+def test_mfma_engine_nan_inf_queries_and_nonfinite_corpus(pn, oracle_mod):
+    pts = uniform((5000, 16), 91, np.float32)
+    qs = uniform((8, 16), 92, np.float32)
+    qs[2, 3] = np.nan
+    qs[5, 0] = np.inf
+    qs[6, :] = 3e19  # squared norm overflows f32
+    tree = _check_knn(pn, oracle_mod, pts, qs, 10, "mfma")
+    assert tree.stats()["fallback_queries"] >= 3
+    bad = pts.copy()
+    bad[17, 2] = np.nan
+    t2 = pn.BallTree.euclidean(bad)
+    assert not t2.mfma_eligible  # non-finite norm: the index is served by the exact engine
+    with pytest.raises(pn.PetalError):
+        t2.set_engine("mfma")
+    idx, dist = t2.query_batch(qs[:2], 10)
+    oidx, odist = oracle_mod.brute_knn(bad, qs[:2], 10)
+    assert _same_dist(dist, odist) and np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("slots", [10, 16, 40])
+def test_mfma_filter_slot_count_does_not_change_results(pn, oracle_mod, slots):
+    from petal_neighbors_amd import _lib
+    pts = uniform((30000, 128), 5, np.float32)
+    qs = uniform((70, 128), 6, np.float32)
+    _check_knn(pn, oracle_mod, pts, qs, 10, "mfma", {_lib.PN_OPT_FILTER_SLOTS: slots, _lib.PN_OPT_SEGMENTS: 3})
+
+
+def test_auto_engine_picks_mfma_and_matches(pn, oracle_mod):
+    pts = uniform((50000, 128), 15, np.float32)
+    qs = uniform((500, 128), 16, np.float32)
+    tree = _check_knn(pn, oracle_mod, pts, qs, 10, "auto")
+    assert tree.mfma_eligible and tree.stats()["candidates"] > 0
 
 
 # --------------------------------------------------------------- radius / pairwise
