@@ -1,0 +1,130 @@
+// petal_neighbors.hpp -- header-only C++17 mirror of petal-neighbors' public API for the
+// hot path (reference src/lib.rs:1-16, src/ball_tree.rs:15-374, src/distance.rs:9-74) over
+// the C ABI in petal_mi355x.h.  Same names, argument meaning and error behaviour as the
+// Rust types; results as std::vector like the Rust `Vec`s.  Link with -lpetal_mi355x.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "petal_mi355x.h"
+
+namespace petal {
+
+// ArrayError (src/lib.rs:9-16)
+struct ArrayError : std::runtime_error {
+    enum Kind { Empty, NotContiguous } kind;
+    ArrayError(Kind k) : std::runtime_error(k == Empty ? "array is empty" : "array is not contiguous in memory"), kind(k) {}
+};
+struct DeviceError : std::runtime_error {
+    int code;
+    DeviceError(int c, const char *m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc == PN_OK) return;
+    if (rc == PN_ERR_EMPTY) throw ArrayError(ArrayError::Empty);
+    if (rc == PN_ERR_NOT_CONTIGUOUS) throw ArrayError(ArrayError::NotContiguous);
+    throw DeviceError(rc, pn_last_error());
+}
+
+namespace distance {
+// Euclidean (src/distance.rs:16-55): zero-sized tag + Metric<A>
+struct Euclidean {
+    bool operator==(const Euclidean &) const { return true; }
+    float distance(const float *a, const float *b, size_t len) const { return pn_euclidean_f32(a, b, len); }
+    double distance(const double *a, const double *b, size_t len) const { return pn_euclidean_f64(a, b, len); }
+    float rdistance(const float *a, const float *b, size_t len) const { return pn_reuclidean_f32(a, b, len); }
+    double rdistance(const double *a, const double *b, size_t len) const { return pn_reuclidean_f64(a, b, len); }
+    float rdistance_to_distance(float d) const { return pn_rdistance_to_distance_f32(d); }
+    double rdistance_to_distance(double d) const { return pn_rdistance_to_distance_f64(d); }
+    float distance_to_rdistance(float d) const { return pn_distance_to_rdistance_f32(d); }
+    double distance_to_rdistance(double d) const { return pn_distance_to_rdistance_f64(d); }
+};
+// pairwise (src/distance.rs:58-74): n x n row-major
+inline std::vector<float> pairwise(const float *x, size_t n, size_t d, int device = 0) {
+    std::vector<float> out(n * n);
+    check(pn_pairwise_f32(x, n, d, (ptrdiff_t)d, device, out.data()));
+    return out;
+}
+inline std::vector<double> pairwise(const double *x, size_t n, size_t d, int device = 0) {
+    std::vector<double> out(n * n);
+    check(pn_pairwise_f64(x, n, d, (ptrdiff_t)d, device, out.data()));
+    return out;
+}
+}  // namespace distance
+
+template <typename A>
+class BallTree {
+    static_assert(std::is_same<A, float>::value || std::is_same<A, double>::value, "A is f32 or f64");
+    pn_index *h_ = nullptr;
+    size_t n_ = 0, dim_ = 0;
+    explicit BallTree(pn_index *h, size_t n, size_t d) : h_(h), n_(n), dim_(d) {}
+
+  public:
+    distance::Euclidean metric;
+    BallTree(BallTree &&o) noexcept : h_(o.h_), n_(o.n_), dim_(o.dim_) { o.h_ = nullptr; }
+    BallTree(const BallTree &) = delete;
+    ~BallTree() { pn_index_destroy(h_); }
+
+    // BallTree::euclidean / ::new (src/ball_tree.rs:38-63, 367-373); strides in elements
+    static BallTree euclidean(const A *points, size_t rows, size_t cols, ptrdiff_t row_stride = -1,
+                              ptrdiff_t col_stride = 1, int device = 0) {
+        pn_index *h = nullptr;
+        if (row_stride < 0) row_stride = (ptrdiff_t)cols;
+        if constexpr (std::is_same<A, float>::value)
+            check(pn_index_create_f32(points, rows, cols, row_stride, col_stride, device, &h));
+        else
+            check(pn_index_create_f64(points, rows, cols, row_stride, col_stride, device, &h));
+        return BallTree(h, rows, cols);
+    }
+    size_t num_points() const { return n_; }  // src/ball_tree.rs:351
+
+    // query (src/ball_tree.rs:102): ascending, min(k, n) results, k == 0 -> empty
+    std::pair<std::vector<size_t>, std::vector<A>> query(const A *point, size_t len, size_t k) const {
+        const size_t kout = k < n_ ? k : n_;
+        std::vector<uint64_t> idx(kout);
+        std::vector<A> dist(kout);
+        if constexpr (std::is_same<A, float>::value)
+            check(pn_query_f32(h_, point, 1, len, (ptrdiff_t)len, k, idx.data(), dist.data()));
+        else
+            check(pn_query_f64(h_, point, 1, len, (ptrdiff_t)len, k, idx.data(), dist.data()));
+        return {std::vector<size_t>(idx.begin(), idx.end()), std::move(dist)};
+    }
+    // query_nearest (src/ball_tree.rs:80)
+    std::pair<size_t, A> query_nearest(const A *point, size_t len) const {
+        uint64_t i = 0;
+        A d = 0;
+        if constexpr (std::is_same<A, float>::value)
+            check(pn_query_nearest_f32(h_, point, 1, len, (ptrdiff_t)len, &i, &d));
+        else
+            check(pn_query_nearest_f64(h_, point, 1, len, (ptrdiff_t)len, &i, &d));
+        return {(size_t)i, d};
+    }
+    // query_radius (src/ball_tree.rs:137); ascending indices
+    std::vector<size_t> query_radius(const A *point, size_t len, A distance) const {
+        uint64_t off[2] = {0, 0};
+        uint64_t *out = nullptr;
+        if constexpr (std::is_same<A, float>::value)
+            check(pn_query_radius_f32(h_, point, 1, len, (ptrdiff_t)len, distance, off, &out));
+        else
+            check(pn_query_radius_f64(h_, point, 1, len, (ptrdiff_t)len, distance, off, &out));
+        std::vector<size_t> v(out, out + off[1]);
+        pn_free(out);
+        return v;
+    }
+    // extension: a batch of points per call (row-major queries), results nq x min(k, n)
+    void query_batch(const A *queries, size_t nq, size_t len, size_t k, uint64_t *idx_out, A *dist_out) const {
+        if constexpr (std::is_same<A, float>::value)
+            check(pn_query_f32(h_, queries, nq, len, (ptrdiff_t)len, k, idx_out, dist_out));
+        else
+            check(pn_query_f64(h_, queries, nq, len, (ptrdiff_t)len, k, idx_out, dist_out));
+    }
+    pn_index *handle() const { return h_; }
+};
+
+}  // namespace petal

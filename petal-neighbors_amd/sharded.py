@@ -119,12 +119,12 @@ class ShardedBallTree:
             kl = li.shape[1]
             idx[:, :kl] = li
             dst[:, :kl] = ld
-        g_idx = self.engine.empty((self.world, nq, k_part), torch.int64)
-        g_dst = self.engine.empty((self.world, nq, k_part), torch.float32)
+        g_idx = self.engine.empty((self.world * nq, k_part), torch.int64)
+        g_dst = self.engine.empty((self.world * nq, k_part), torch.float32)
         # the one exchange step of the path: all-gather of per-shard top-k (RCCL over xGMI)
         self.dist.all_gather_into_tensor(g_idx, idx, group=self.group)
         self.dist.all_gather_into_tensor(g_dst, dst, group=self.group)
-        return self.engine.merge(g_idx, g_dst, k_out)
+        return self.engine.merge(g_idx.view(self.world, nq, k_part), g_dst.view(self.world, nq, k_part), k_out)
 
     def query(self, point, k: int):
         i, d = self.query_batch(point.reshape(1, -1), k)

@@ -1,0 +1,133 @@
+"""Row-sharded host logic (petal-neighbors_amd/sharded.py) at world size 2 and 3 over gloo, CPU only.
+
+The per-rank engine is replaced by a test double backed by the ORACLE (tests may use it); what is
+under test is the product's host logic: shard bounds, global index bases, padding of short shards,
+the single all-gather per batch, the merge call pattern and the radius concatenation.  The HIP
+engine + HIP merge kernel are covered by the `-m gpu` tests (test_gpu_sharded.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, uniform
+
+ABSENT = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+class OracleShardEngine:
+    """CPU test double with the HipShardEngine interface."""
+
+    def __init__(self):
+        import oracle
+        self.o = oracle
+        self.pts = None
+        self.lo = 0
+
+    def build(self, rows, lo):
+        self.pts = np.ascontiguousarray(rows, dtype=np.float32)
+        self.lo = lo
+
+    def query(self, queries, k):
+        i, d = self.o.brute_knn(self.pts, queries.numpy(), k)
+        return torch.from_numpy((i + np.uint64(self.lo)).astype(np.int64)), torch.from_numpy(d)
+
+    def radius(self, queries, r):
+        q = queries.numpy()
+        off = np.zeros(len(q) + 1, dtype=np.uint64)
+        parts = []
+        for a in range(len(q)):
+            ids = self.o.brute_radius(self.pts, q[a], np.float32(r)) + np.uint64(self.lo)
+            parts.append(ids)
+            off[a + 1] = off[a] + np.uint64(len(ids))
+        return off, (np.concatenate(parts) if parts else np.empty(0, dtype=np.uint64))
+
+    def merge(self, idx_parts, dist_parts, k_out):
+        """(G, nq, kp) -> (nq, k_out) by (distance total order, index); index -1 = absent."""
+        g, nq, kp = idx_parts.shape
+        ii = idx_parts.numpy().astype(np.uint64).transpose(1, 0, 2).reshape(nq, g * kp)
+        dd = dist_parts.numpy().transpose(1, 0, 2).reshape(nq, g * kp)
+        oi = np.full((nq, k_out), -1, dtype=np.int64)
+        od = np.full((nq, k_out), np.nan, dtype=np.float32)
+        for a in range(nq):
+            ent = [(np.inf if np.isnan(d) else d, bool(np.isnan(d)), int(i)) for i, d in zip(ii[a], dd[a]) if i != ABSENT]
+            ent.sort(key=lambda t: (t[1], t[0], t[2]))
+            for j, (d, isn, i) in enumerate(ent[:k_out]):
+                oi[a, j] = i
+                od[a, j] = np.nan if isn else d
+        return torch.from_numpy(oi), torch.from_numpy(od)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, dim, nq, k, r, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from petal_neighbors_amd.sharded import ShardedBallTree
+        from conftest import uniform as uni
+        pts = uni((n, dim), 1234, np.float32)
+        if n > 40:
+            pts[n // 2] = pts[3]  # an exact duplicate across shards: tie broken by global index
+        h = min(5, n)
+        qs = torch.from_numpy(np.concatenate([pts[:h], uni((nq - h, dim), 99, np.float32)]))
+        index = ShardedBallTree(n, lambda lo, hi: pts[lo:hi], engine=OracleShardEngine())
+        idx, dst = index.query_batch(qs, k)
+        off, ids = index.query_radius_batch(qs, r)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx.numpy(), dst=dst.numpy(), off=off, ids=ids,
+                 lo=index.lo, hi=index.hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,k", [(2, 1001, 10), (2, 30, 25), (3, 200, 7), (2, 1, 3)])
+def test_sharded_query_matches_single_index(tmp_path, oracle_mod, world, n, k):
+    dim, nq, r = 6, 9, 0.45
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, dim, nq, k, r, str(tmp_path)), nprocs=world, join=True)
+    pts = uniform((n, dim), 1234, np.float32)
+    if n > 40:
+        pts[n // 2] = pts[3]
+    h = min(5, n)
+    qs = np.concatenate([pts[:h], uniform((nq - h, dim), 99, np.float32)])
+    want_i, want_d = oracle_mod.brute_knn(pts, qs, k)
+    covered = []
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert z["idx"].shape == (nq, min(k, n))
+        assert np.array_equal(z["idx"].astype(np.uint64), want_i), f"rank {rank}"
+        assert z["dst"].tobytes() == want_d.tobytes(), f"rank {rank}"
+        for a in range(nq):
+            want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+            got = z["ids"][int(z["off"][a]):int(z["off"][a + 1])]
+            assert np.array_equal(got, want), (rank, a)
+        covered.append((int(z["lo"]), int(z["hi"])))
+    assert covered[0][0] == 0 and covered[-1][1] == n
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))
+
+
+def test_shard_bounds_partition():
+    from petal_neighbors_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 9, 1_000_000, 100_000_001):
+        for w in (1, 2, 3, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) == -(-n // w) or n == 0
