@@ -33,6 +33,8 @@ UNITS = [
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+# diagnostic (timing-only) builds: PN_DIAG_FLAGS="-DPN_DIAG_NO_SLOWPATH" python build.py --force
+DIAG = os.environ.get("PN_DIAG_FLAGS", "").split()
 HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
 
 
@@ -61,13 +63,13 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
         objs.append(obj)
         if force or _stale(obj, [sp, me] + HEADERS):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
-            cmd = [cc] + COMMON + extra + lang + ["-c", sp, "-o", obj]
+            cmd = [cc] + COMMON + extra + DIAG + lang + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
         asm = os.path.join(BUILD, os.path.splitext(src)[0] + ".s")
         if keep_asm and src.endswith(".hip") and (force or _stale(asm, [sp, me] + HEADERS)):
-            cmd = [cc] + COMMON + extra + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
+            cmd = [cc] + COMMON + extra + DIAG + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs

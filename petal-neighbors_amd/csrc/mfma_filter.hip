@@ -96,17 +96,20 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(
     // lambda / helper / macro-wrapped loop is not unrolled early enough and sends st[] to scratch.
     f32x4 st[NLD];
     float stn = 0.0f;
+    const uint32_t lane_off = (uint32_t)tid * 16u;
 
     float tau = __uint_as_float(0x7F800000u);
     if (p_begin < p_end) {
         {
-            const f32x4 *src_ = reinterpret_cast<const f32x4 *>(P + (p_begin) * LD);
+            // uniform (SGPR) tile base + loop-invariant per-lane byte offset -> saddr-form loads whose
+            // address VGPR is never recycled as an MFMA destination
+            const char *src_ = reinterpret_cast<const char *>(P) + (p_begin) * (size_t)(LD * 4);
 #pragma unroll
             for (int i_ = 0; i_ < NLD; ++i_) {
-                const int c_ = tid + 256 * i_;
-                if (CHUNKS % 256 == 0 || c_ < CHUNKS) st[i_] = src_[c_];
+                if (CHUNKS % 256 == 0 || tid + 256 * i_ < CHUNKS)
+                    st[i_] = *reinterpret_cast<const f32x4 *>(src_ + (lane_off + 4096u * i_));
             }
-            if (tid < kMfP) stn = pnorm[(p_begin) + tid];
+            stn = pnorm[(p_begin) + (tid & 63)];  // unconditional: a branch here costs a vmcnt(0) in the MFMA chain
         }
         {
             float *dst_ = tiles + (0) * kMfP * STR;
@@ -128,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(
         const bool more = p0 + kMfP < p_end;
         if (more)
         {
-            const f32x4 *src_ = reinterpret_cast<const f32x4 *>(P + (p0 + kMfP) * LD);
+            const char *src_ = reinterpret_cast<const char *>(P) + (p0 + kMfP) * (size_t)(LD * 4);
 #pragma unroll
             for (int i_ = 0; i_ < NLD; ++i_) {
-                const int c_ = tid + 256 * i_;
-                if (CHUNKS % 256 == 0 || c_ < CHUNKS) st[i_] = src_[c_];
+                if (CHUNKS % 256 == 0 || tid + 256 * i_ < CHUNKS)
+                    st[i_] = *reinterpret_cast<const f32x4 *>(src_ + (lane_off + 4096u * i_));
             }
-            if (tid < kMfP) stn = pnorm[(p0 + kMfP) + tid];
+            stn = pnorm[(p0 + kMfP) + (tid & 63)];
         }
 
         const float *tl = tiles + cur * kMfP * STR + jq * STR + 4 * h;
@@ -147,25 +150,59 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, acc1, 0, 0, 0);
         }
+        {
+            // fragment reads run ONE k-group (8 MFMAs = 512 cycles) ahead of their use: a b128 LDS
+            // read issued only two MFMAs early does not land in time when 8 waves share the LDS
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(tl);
+            f32x4 a1 = *reinterpret_cast<const f32x4 *>(tl + 32 * STR);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // group 0's reads
 #pragma unroll
-        for (int kg = 0; kg < NKG; ++kg) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(tl + 8 * kg);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(tl + 32 * STR + 8 * kg);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[4 * kg + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[4 * kg + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[4 * kg + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[4 * kg + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[4 * kg + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[4 * kg + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[4 * kg + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[4 * kg + 3], acc1, 0, 0, 0);
+            for (int kg = 0; kg < NKG; ++kg) {
+                f32x4 n0 = a0, n1 = a1;
+                if (kg + 1 < NKG) {
+                    n0 = *reinterpret_cast<const f32x4 *>(tl + 8 * (kg + 1));
+                    n1 = *reinterpret_cast<const f32x4 *>(tl + 32 * STR + 8 * (kg + 1));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the two DS reads first ...
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[4 * kg + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[4 * kg + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[4 * kg + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[4 * kg + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[4 * kg + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[4 * kg + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[4 * kg + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[4 * kg + 3], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // ... then this group's 8 MFMAs
+                a0 = n0;
+                a1 = n1;
+            }
         }
 
         // ---- fused filter: the lane holds 32 lower bounds of ITS query
         float m = fminf(acc0[0], acc1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = fminf(m, fminf(acc0[r], acc1[r]));
+        // Staged tile -> LDS first: its wait retires the prefetch loads, so the (rare) slow path below
+        // starts with an empty VMEM queue and can drain its own stores cheaply.
+        if (more)
+        {
+            float *dst_ = tiles + (cur ^ 1) * kMfP * STR;
+#pragma unroll
+            for (int i_ = 0; i_ < NLD; ++i_) {
+                const int c_ = tid + 256 * i_;
+                if (CHUNKS % 256 == 0 || c_ < CHUNKS) {
+                    const int row_ = c_ / (LD / 4), cc_ = c_ % (LD / 4);
+                    *reinterpret_cast<f32x4 *>(dst_ + row_ * STR + 4 * cc_) = st[i_];
+                }
+            }
+            if (tid < kMfP) pnl[(cur ^ 1) * kMfP + tid] = stn;
+        }
+#ifdef PN_DIAG_NO_SLOWPATH  // timing-only diagnostic build: results are wrong, never shipped
+        asm volatile("" ::"v"(m));
+        if (false) {
+#else
         if (__any(m < tau)) {
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t row = (uint32_t)p0 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D map of 32x32
@@ -193,21 +230,11 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(
                                            &cnts_w[j], 0xFFFFFFFFu);
             }
             tau = s2f(taus_w[jq]);
+            // Leave no candidate store pending: a mix of pending stores and the next tile's prefetch
+            // loads makes hipcc's wait-count pass emit vmcnt(0) inside the next MFMA chain.
+            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
         }
 
-        if (more)
-        {
-            float *dst_ = tiles + (cur ^ 1) * kMfP * STR;
-#pragma unroll
-            for (int i_ = 0; i_ < NLD; ++i_) {
-                const int c_ = tid + 256 * i_;
-                if (CHUNKS % 256 == 0 || c_ < CHUNKS) {
-                    const int row_ = c_ / (LD / 4), cc_ = c_ % (LD / 4);
-                    *reinterpret_cast<f32x4 *>(dst_ + row_ * STR + 4 * cc_) = st[i_];
-                }
-            }
-            if (tid < kMfP) pnl[(cur ^ 1) * kMfP + tid] = stn;
-        }
         __syncthreads();
     }
 
