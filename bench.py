@@ -44,15 +44,35 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP
 SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
 
 
-def cpu_baseline(n, dim, k, budget_queries=None):
-    """Faithful ball tree (oracle/oracle_impl.h) on this host: all-core QPS, single-thread QPS, build s."""
-    import oracle
-    oracle.build()
+def usable_cores():
+    """CPU threads this process may actually run: affinity mask, capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline(n, dim, k, budget_queries=None):
+    """Faithful ball tree (oracle/oracle_impl.h) on this host: all-core QPS, single-thread QPS, build s."""
+    import oracle
+    oracle.build()
+    cores = usable_cores()
     n_cpu = min(n, 1_000_000)
     pts = oracle.fill_uniform(n_cpu * dim, SEED_P).reshape(n_cpu, dim)
     par = max(0, min(4, int(np.log2(max(cores, 1)))))
@@ -86,6 +106,8 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "exact", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
+    ap.add_argument("--structure", type=int, default=0, help="PN_OPT_MFMA_STRUCTURE; 0 = auto")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +143,10 @@ def main():
     tree.set_engine(args.engine)
     if args.segments:
         tree.set_option(_lib.PN_OPT_SEGMENTS, args.segments)
+    if args.slots:
+        tree.set_option(_lib.PN_OPT_FILTER_SLOTS, args.slots)
+    if args.structure:
+        tree.set_option(_lib.PN_OPT_MFMA_STRUCTURE, args.structure)
     tree.set_option(_lib.PN_OPT_PROFILE, 1)
     n_local = index.n_local
     torch.cuda.synchronize()
@@ -169,7 +195,8 @@ def main():
                        "sharding": f"corpus rows / {world}" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "mfma_filter_kernel" if engine_used == "mfma" else "exact_knn_kernel",
+                         "kernel": ("mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
+                                    else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel",
                          "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
                                                   / (PEAK_F32_MFMA_TFLOPS * world), 4)},

@@ -70,7 +70,8 @@ enum {
     PN_OPT_SEGMENTS = 2,    /* corpus row segments per query tile; 0 = auto */
     PN_OPT_INDEX_BASE = 3,  /* added to every returned index (row-sharded corpora) */
     PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream */
-    PN_OPT_FILTER_SLOTS = 5 /* k' kept by the MFMA filter per (query, segment); 0 = auto */
+    PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
+    PN_OPT_MFMA_STRUCTURE = 6 /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent balanced partition */
 };
 
 typedef struct pn_index pn_index;

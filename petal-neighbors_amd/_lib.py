@@ -15,6 +15,7 @@ PN_OK, PN_ERR_EMPTY, PN_ERR_NOT_CONTIGUOUS, PN_ERR_INVALID, PN_ERR_DEVICE, PN_ER
     PN_ERR_UNSUPPORTED, PN_ERR_EMPTY_MATRIX = range(8)
 PN_ENGINE_AUTO, PN_ENGINE_EXACT, PN_ENGINE_MFMA = 0, 1, 2
 PN_OPT_ENGINE, PN_OPT_SEGMENTS, PN_OPT_INDEX_BASE, PN_OPT_PROFILE, PN_OPT_FILTER_SLOTS = 1, 2, 3, 4, 5
+PN_OPT_MFMA_STRUCTURE = 6
 
 
 class PnInfo(C.Structure):

@@ -29,6 +29,7 @@ UNITS = [
     ("select.hip", ["-ffp-contract=off"]),
     ("pack.hip", []),
     ("mfma_filter.hip", []),
+    ("mfma_filter_v2.hip", []),
     ("metric.cpp", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -165,15 +165,21 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
         }
         if (__any(anyp)) {  // wave-uniform slow path: append, then compact where nearly full
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
+                uint32_t np = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (key[a][b] < tau_r[a]) {
-                        const uint32_t slot = atomicAdd(&cnts[qb + a], 1u);
-                        const size_t o = cbase0 + (size_t)(qb + a) * CAP + slot;
-                        ckey[o] = key[a][b];
-                        cidx[o] = (uint32_t)(p0 + pb + b);
-                    }
+                for (int b = 0; b < 4; ++b) np += key[a][b] < tau_r[a] ? 1u : 0u;
+                if (np) {  // one LDS atomic per (lane, query) reserves room for its survivors
+                    size_t o = cbase0 + (size_t)(qb + a) * CAP + atomicAdd(&cnts[qb + a], np);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (key[a][b] < tau_r[a]) {
+                            ckey[o] = key[a][b];
+                            cidx[o] = (uint32_t)(p0 + pb + b);
+                            ++o;
+                        }
+                }
+            }
             wg_fence();
             for (int j = 0; j < 16; ++j) {
                 const int qj = wave * 16 + j;

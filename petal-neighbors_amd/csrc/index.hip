@@ -103,6 +103,7 @@ struct pn_index {
     void *d_pts = nullptr;   // [n_pad][ld], zero padded
     float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
     bool mfma_ok = false;
+    int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
     hipStream_t stream = nullptr;
     // options
     int engine = PN_ENGINE_AUTO;
@@ -110,6 +111,7 @@ struct pn_index {
     uint64_t index_base = 0;
     int profile = 0;
     int filter_slots = 0;
+    int mfma_structure = 0;  // 0 auto, 1 = grid of (query tile x segment), 2 = persistent balanced partition
     // per-call scratch, serialised by `mu`
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
@@ -156,6 +158,11 @@ static float mfma_alpha(size_t dim) {
 template <typename T>
 static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStream_t s) {
     // d_src: device rows [n][row_stride] (inner stride 1) -> padded layout + norms
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0)
+            ix->n_cu = prop.multiProcessorCount;
+    }
     const size_t bytes = ix->n_pad * ix->ld * sizeof(T);
     HIPCHK(hipMalloc(&ix->d_pts, bytes ? bytes : 256));
     if (sizeof(T) == 4)
@@ -336,6 +343,10 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             if (value < 0 || value > 960) return fail(PN_ERR_INVALID, "bad filter slot count");
             ix->filter_slots = (int)value;
             return PN_OK;
+        case PN_OPT_MFMA_STRUCTURE:
+            if (value < 0 || value > 2) return fail(PN_ERR_INVALID, "bad structure");
+            ix->mfma_structure = (int)value;
+            return PN_OK;
         default: return fail(PN_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -459,9 +470,16 @@ static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, 
 
 static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
                     float *d_dist, hipStream_t s);
-static size_t mfma_slots(const pn_index *ix, size_t kout) {
-    size_t kp = ix->filter_slots > 0 ? (size_t)ix->filter_slots : kout + (kout < 16 ? 6 : kout / 4 + 4);
-    return kp < kout ? kout : kp;
+// k' kept by the filter per (segment, query).  The proof in select.hip needs every segment's k'-th
+// lower bound to clear the GLOBAL k-th exact distance; with >= 3 segments per query tile (always the
+// case for the persistent partition when query tiles <= CUs / 3) a segment's k'-th bound is far above
+// it even for k' = k + 2, and every extra slot costs appends.  Otherwise keep a wider margin.
+static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
+    if (ix->filter_slots > 0) return (size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots;
+    const size_t q_tiles = nq_pad / 128;
+    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu && kout + 2 <= 30;
+    if (many_segments) return kout + 2;
+    return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
 
 template <typename T>
@@ -495,7 +513,7 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
         bool use_mfma = false;
         if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
             // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
-            use_mfma = mfma_slots(ix, kout) + 64 <= 256;
+            use_mfma = mfma_slots(ix, kout, nq_pad) + 64 <= 256;
             if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
         }
         if (use_mfma)
@@ -518,8 +536,9 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
 static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
                     float *d_dist, hipStream_t s) {
     // candidate slots kept per (segment, query)
-    const size_t kp = mfma_slots(ix, kout);
-    int cap = pick_cap(kp);
+    const size_t kp = mfma_slots(ix, kout, nq_pad);
+    const bool v2 = kp <= 30 && ix->mfma_structure != 1;  // 64 LDS slots, compaction above 32 in use
+    int cap = v2 ? 32 : pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
     // scaled query norms (same kernel as the corpus norms)
     PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
@@ -530,19 +549,44 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
     HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
                                 d_nflag + 1, s));
-    const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192, 512, true);
-    MfmaPlan plan{sp.nseg, sp.seg_len, (int)kp, cap};
-    const size_t slots = (size_t)plan.nseg * nq_pad * (size_t)cap;
+    MfmaPlan plan{};
+    int n_wg = ix->n_cu;
+    if (v2) {
+        // at most ~32 workgroups per query tile and at least ~32 row tiles per workgroup
+        const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
+        size_t cap_wg = q_tiles * 32;
+        const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+        if (by_work < cap_wg) cap_wg = by_work;
+        if (cap_wg < 1) cap_wg = 1;
+        if ((size_t)n_wg > cap_wg) n_wg = (int)cap_wg;
+        plan.nseg = mfma_v2_max_segments(nq_pad / 128, n_wg);
+        plan.seg_len = 0;
+        plan.kp = (int)kp;
+        plan.cap = cap;
+    } else {
+        const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192, 512, true);
+        plan = MfmaPlan{sp.nseg, sp.seg_len, (int)kp, cap};
+    }
+    const size_t cells = (size_t)plan.nseg * nq_pad;
+    const size_t slots = cells * (size_t)cap;
     PNCHK(ix->w_keys.ensure(slots * sizeof(uint32_t)));
     PNCHK(ix->w_idx.ensure(slots * sizeof(uint32_t)));
-    PNCHK(ix->w_cnt.ensure((size_t)plan.nseg * nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_tau.ensure((size_t)plan.nseg * nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
     PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));
     CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_idx.p, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, plan.nseg, cap};
+    if (v2) {  // not every (segment, query tile) cell is written by the persistent partition
+        HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+    }
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld, Qp,
-                                  (const float *)ix->w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
+    if (v2)
+        HIPCHK(launch_mfma_filter_v2_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp,
+                                         (const float *)ix->w_qnorm.p, ix->ld, (int)kp, cb, n_wg, s));
+    else
+        HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld,
+                                      Qp, (const float *)ix->w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_flags.p, d_nflag,

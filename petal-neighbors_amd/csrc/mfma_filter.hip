@@ -203,20 +203,33 @@ __global__ __launch_bounds__(256, 2) void mfma_filter_kernel(
 #else
         if (__any(m < tau)) {
 #endif
+            // one LDS atomic per lane reserves room for all of its survivors
+            uint32_t mask0 = 0, mask1 = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t row = (uint32_t)p0 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D map of 32x32
-                if (acc0[r] < tau) {
-                    const uint32_t slot = atomicAdd(&cnts_w[jq], 1u);
-                    const size_t o = cbase + (size_t)jq * CAP + slot;
-                    ckey[o] = f2s(acc0[r]);
-                    cidx[o] = row;
+                mask0 |= (acc0[r] < tau ? 1u : 0u) << r;
+                mask1 |= (acc1[r] < tau ? 1u : 0u) << r;
+            }
+            const uint32_t npass = (uint32_t)__popc(mask0) + (uint32_t)__popc(mask1);
+            if (npass) {
+                size_t o = cbase + (size_t)jq * CAP + atomicAdd(&cnts_w[jq], npass);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (uint32_t)p0 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D map of 32x32
+                    if (mask0 & (1u << r)) {
+                        ckey[o] = f2s(acc0[r]);
+                        cidx[o] = row;
+                        ++o;
+                    }
                 }
-                if (acc1[r] < tau) {
-                    const uint32_t slot = atomicAdd(&cnts_w[jq], 1u);
-                    const size_t o = cbase + (size_t)jq * CAP + slot;
-                    ckey[o] = f2s(acc1[r]);
-                    cidx[o] = row + 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (uint32_t)p0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (mask1 & (1u << r)) {
+                        ckey[o] = f2s(acc1[r]);
+                        cidx[o] = row;
+                        ++o;
+                    }
                 }
             }
             wg_fence();

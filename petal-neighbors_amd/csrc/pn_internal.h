@@ -107,5 +107,10 @@ hipError_t launch_mfma_filter_f32(const float *P, const float *pnorm, size_t n, 
                                   size_t ldp, const float *Q, const float *qnorm, int nq, size_t ldq,
                                   const MfmaPlan &plan, const CandBuf &cb, hipStream_t s);
 const char *mfma_kernel_name();
+// second structure (mfma_filter_v2.hip): persistent balanced partition, k' <= 32, 32 slots per (segment, query)
+int mfma_v2_max_segments(size_t q_tiles, int n_wg);
+hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
+                                     const float *qnorm, size_t ldq, int kp, const CandBuf &cb, int n_wg,
+                                     hipStream_t s);
 
 }  // namespace pn

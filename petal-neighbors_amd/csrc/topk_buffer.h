@@ -29,46 +29,81 @@ __device__ __forceinline__ void wg_fence() {
 }
 
 // ---------------------------------------------------------------------------
-// Rank-and-keep compaction of one query's candidate buffer by its owning wave.
+// Compaction of one query's buffer by its owning wave: keep the kp smallest
+// entries under the total order (key, row) and lower tau to the kp-th key.
+//
+// Radix select instead of sorting: the kp-th smallest key T is found one bit at
+// a time, each step a ballot + popcount over the wave (32 or 64 steps of a few
+// scalar instructions, independent of the buffer size).  Entries with key < T
+// are kept; of the entries with key == T the (kp - #less) smallest rows are
+// kept, found by the same bit-wise select on the row index when there are more
+// ties than room.  Survivors are written back compactly (unordered: the select
+// kernel ranks them at the end).  Requires n > kp.
 // ---------------------------------------------------------------------------
 template <typename KeyT, int M>
 __device__ __forceinline__ void compact_query(KeyT *__restrict__ ckey, uint32_t *__restrict__ cidx, size_t base,
                                               uint32_t n, uint32_t kp, int lane, KeyT *tau_slot,
                                               uint32_t *cnt_slot, KeyT key_max) {
     KeyT key[M];
-    uint32_t ix[M], rank[M];
+    uint32_t ix[M];
+    bool valid[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const uint32_t slot = m * 64 + lane;
-        const bool v = slot < n;
-        key[m] = v ? ckey[base + slot] : key_max;
-        ix[m] = v ? cidx[base + slot] : 0xFFFFFFFFu;
-        rank[m] = 0;
+        valid[m] = slot < n;
+        key[m] = valid[m] ? ckey[base + slot] : key_max;
+        ix[m] = valid[m] ? cidx[base + slot] : 0xFFFFFFFFu;
     }
+    // T = kp-th smallest key: the largest T with #{key < T} < kp
+    KeyT T = 0;
+    for (int bit = (int)sizeof(KeyT) * 8 - 1; bit >= 0; --bit) {
+        const KeyT cand = T | ((KeyT)1 << bit);
+        uint32_t cnt = 0;
 #pragma unroll
-    for (int m2 = 0; m2 < M; ++m2) {
-        int lim = (int)n - m2 * 64;
-        lim = lim > 64 ? 64 : lim;
-        for (int ln = 0; ln < lim; ++ln) {
-            const KeyT bk = bcast_lane(key[m2], ln);
-            const uint32_t bi = bcast_lane(ix[m2], ln);
-#pragma unroll
-            for (int m = 0; m < M; ++m)
-                rank[m] += ((bk < key[m]) || (bk == key[m] && bi < ix[m])) ? 1u : 0u;
-        }
+        for (int m = 0; m < M; ++m) cnt += (uint32_t)__popcll(__ballot(valid[m] && key[m] < cand));
+        if (cnt < kp) T = cand;
     }
+    uint32_t n_less = 0, n_eq = 0;
+    bool sel[M], eq[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        if ((uint32_t)(m * 64 + lane) < n && rank[m] < kp) {
-            ckey[base + rank[m]] = key[m];
-            cidx[base + rank[m]] = ix[m];
-            if (rank[m] == kp - 1) *tau_slot = key[m];
-        }
+        sel[m] = valid[m] && key[m] < T;
+        eq[m] = valid[m] && key[m] == T;
+        n_less += (uint32_t)__popcll(__ballot(sel[m]));
+        n_eq += (uint32_t)__popcll(__ballot(eq[m]));
     }
-    if (lane == 0) *cnt_slot = n < kp ? n : kp;
+    const uint32_t need_eq = kp - n_less;  // >= 1
+    uint32_t row_cut = 0xFFFFFFFFu;         // keep ties with row <= row_cut
+    if (n_eq > need_eq) {                   // more ties than room: the need_eq smallest rows win
+        uint32_t I = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = I | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) cnt += (uint32_t)__popcll(__ballot(eq[m] && ix[m] < cand));
+            if (cnt < need_eq) I = cand;
+        }
+        row_cut = I;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t pos = 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const bool keep = sel[m] || (eq[m] && ix[m] <= row_cut);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const uint32_t o = pos + (uint32_t)__popcll(mask & lt);
+            ckey[base + o] = key[m];
+            cidx[base + o] = ix[m];
+        }
+        pos += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) {
+        *tau_slot = T;
+        *cnt_slot = pos;  // == kp
+    }
     wg_fence();
 }
-
 
 // order-preserving float <-> uint32 map (negative lower bounds occur)
 __device__ __forceinline__ uint32_t f2s(float f) {
