@@ -15,8 +15,8 @@
  *   - strides are in ELEMENTS, not bytes.
  *   - "host" entry points take host pointers (what an ndarray hands over) and
  *     do the PCIe transfers themselves; "_device" entry points take pointers
- *     into the index's GPU memory and a hipStream_t (as void*; NULL = the
- *     index's own stream) and enqueue work without copying inputs.
+ *     into the index's GPU memory and a hipStream_t (as void*; NULL = HIP's
+ *     default stream) and enqueue work on that stream without copying inputs.
  *   - results are written into caller-allocated buffers; the only
  *     library-allocated result (radius CSR indices) is released with pn_free.
  *   - all query functions are re-entrant on a shared `const pn_index*`

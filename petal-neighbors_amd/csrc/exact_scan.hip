@@ -119,7 +119,8 @@ template <typename T, int M>
 __global__ __launch_bounds__(256) void exact_knn_kernel(
     const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq,
     uint32_t kp, size_t seg_len, typename KeyOf<T>::type *__restrict__ ckey, uint32_t *__restrict__ cidx,
-    uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad) {
+    uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad,
+    const typename KeyOf<T>::type *__restrict__ lo_key, const uint32_t *__restrict__ lo_idx) {
     using KeyT = typename KeyOf<T>::type;
     constexpr uint32_t CAP = 64u * M;
     constexpr KeyT KMAX = KeyOf<T>::kMax;
@@ -142,6 +143,16 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 
     const T *Qt = Q + q0 * ldq;
     const size_t cbase0 = (seg * nq_pad + q0) * (size_t)CAP;
+    // multi-round selection (k beyond one buffer): only entries strictly after (lo_key, lo_idx) in the
+    // (key, row) order take part, i.e. the neighbours already returned by earlier rounds are skipped
+    KeyT lok[4];
+    uint32_t loi[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        lok[a] = lo_key ? lo_key[q0 + qb + a] : (KeyT)0;
+        loi[a] = lo_key ? lo_idx[q0 + qb + a] : 0u;
+    }
+    const bool bounded = lo_key != nullptr;
     bool first = true;
     for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
         T acc[4][4];
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const bool v = qv && (p0 + pb + b) < p_end;
-                const KeyT kk = v ? dist_key(pn_sqrt(acc[a][b])) : KMAX;
+                KeyT kk = v ? dist_key(pn_sqrt(acc[a][b])) : KMAX;
+                if (bounded && !(kk > lok[a] || (kk == lok[a] && (uint32_t)(p0 + pb + b) > loi[a]))) kk = KMAX;
                 key[a][b] = kk;
                 anyp |= kk < tau_r[a];
             }
@@ -207,14 +219,16 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 
 template <typename T>
 static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
-                                   int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
+                                   int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
+                                   const uint32_t *lo_idx, hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
     auto *ck = static_cast<KeyT *>(cb.keys);
     auto *ct = static_cast<KeyT *>(cb.tau);
 #define PN_LAUNCH(MM)                                                                                    \
     hipLaunchKernelGGL((exact_knn_kernel<T, MM>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,          \
-                       (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad)
+                       (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad, static_cast<const KeyT *>(lo_key),  \
+                       lo_idx)
     switch (cb.cap / 64) {
         case 2: PN_LAUNCH(2); break;
         case 4: PN_LAUNCH(4); break;
@@ -227,12 +241,14 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
 }
 
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
-                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
-    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
+                                const uint32_t *lo_idx, hipStream_t s) {
+    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, s);
 }
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
-                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s) {
-    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
+                                const uint32_t *lo_idx, hipStream_t s) {
+    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -115,7 +115,7 @@ struct pn_index {
     // per-call scratch, serialised by `mu`
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
-    mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau;
+    mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
     mutable pn_stats stats{};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
@@ -297,10 +297,12 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
 extern "C" void pn_index_destroy(pn_index *ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
-    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    // queries may have been enqueued on caller streams (the *_device entry points): nothing of this
+    // index may be freed while any of them is still running
+    (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ix->w_q, &ix->w_qnorm, &ix->w_keys, &ix->w_idx, &ix->w_cnt, &ix->w_tau, &ix->w_flags,
                       &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
-                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau};
+                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
@@ -414,11 +416,12 @@ template <> struct Ops<float> {
         return launch_pack_rows_f32(s, n, c, rs, d, np, ld, st);
     }
     static hipError_t knn(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, int kp,
-                          size_t seg_len, const CandBuf &cb, hipStream_t s) {
-        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, hipStream_t s) {
+        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, s);
     }
-    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, hipStream_t s) {
-        return launch_select_exact_f32(cb, nq, kout, base, io, dd, s);
+    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, size_t os,
+                             size_t oo, void *lk, uint32_t *li, hipStream_t s) {
+        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, s);
     }
 };
 template <> struct Ops<double> {
@@ -426,11 +429,12 @@ template <> struct Ops<double> {
         return launch_pack_rows_f64(s, n, c, rs, d, np, ld, st);
     }
     static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
-                          size_t seg_len, const CandBuf &cb, hipStream_t s) {
-        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, s);
+                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, hipStream_t s) {
+        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, s);
     }
-    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, hipStream_t s) {
-        return launch_select_exact_f64(cb, nq, kout, base, io, dd, s);
+    static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os,
+                             size_t oo, void *lk, uint32_t *li, hipStream_t s) {
+        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, s);
     }
 };
 
@@ -439,9 +443,11 @@ template <typename T>
 static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
                      uint64_t *d_idx, T *d_dist, hipStream_t s, bool second_set, bool hot) {
     using KeyT = typename KeyOf<T>::type;
-    const int cap = pick_cap(kout);
-    if (!cap)
-        return fail(PN_ERR_UNSUPPORTED, "k = %zu exceeds the single-pass limit of 960 neighbours", kout);
+    // k beyond one candidate buffer (960 slots): rounds of <= 960 neighbours, each resuming strictly
+    // after the last (distance key, row) of the previous one
+    const size_t kRound = 960;
+    const size_t k_first = kout < kRound ? kout : kRound;
+    const int cap = pick_cap(k_first);
     const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, cap, ix->opt_segments, 4096, 4096);
     DevBuf &bk = second_set ? ix->w2_keys : ix->w_keys;
     DevBuf &bi = second_set ? ix->w2_idx : ix->w_idx;
@@ -453,11 +459,22 @@ static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, 
     PNCHK(bc.ensure((size_t)pl.nseg * nq_pad * sizeof(uint32_t)));
     PNCHK(bt.ensure((size_t)pl.nseg * nq_pad * sizeof(KeyT)));
     CandBuf cb{bk.p, (uint32_t *)bi.p, (uint32_t *)bc.p, bt.p, nq_pad, pl.nseg, cap};
+    void *lo_key = nullptr;
+    uint32_t *lo_idx = nullptr;
+    if (kout > kRound) {
+        PNCHK(ix->w_lo.ensure(nq_pad * (sizeof(KeyT) + sizeof(uint32_t))));
+        lo_key = ix->w_lo.p;
+        lo_idx = (uint32_t *)((char *)ix->w_lo.p + nq_pad * sizeof(KeyT));
+    }
     const bool prof = hot && ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kout, pl.seg_len, cb, s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
-    HIPCHK(Ops<T>::select(cb, (int)nq, (int)kout, ix->index_base, d_idx, d_dist, s));
+    for (size_t done = 0; done < kout; done += kRound) {
+        const size_t kr = kout - done < kRound ? kout - done : kRound;
+        HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kr, pl.seg_len, cb,
+                           done ? lo_key : nullptr, done ? lo_idx : nullptr, s));
+        if (prof && done == 0) HIPCHK(hipEventRecord(ix->ev1, s));
+        HIPCHK(Ops<T>::select(cb, (int)nq, (int)kr, ix->index_base, d_idx, d_dist, kout, done, lo_key, lo_idx, s));
+    }
     if (prof) {
         HIPCHK(hipEventSynchronize(ix->ev1));
         float ms = 0;
@@ -495,7 +512,8 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
     std::lock_guard<std::mutex> lk(ix->mu);
-    if (!s) s = ix->stream;
+    // s == NULL is HIP's default stream (what torch.cuda.current_stream() is unless changed): work is
+    // ordered with the caller's other default-stream work, as a caller of a *_device entry point expects
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;  // zip truncation (src/distance.rs:27-28)
     if (ix->profile) {
         PNCHK(ensure_events(ix));

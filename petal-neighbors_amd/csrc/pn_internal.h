@@ -46,10 +46,13 @@ struct CandBuf {
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // ---- exact_scan.hip
+// lo_key/lo_idx (nullable, [nq_pad]): only entries strictly after (lo_key[q], lo_idx[q]) take part
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
-                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s);
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
+                                const uint32_t *lo_idx, hipStream_t s);
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
-                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, hipStream_t s);
+                                size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
+                                const uint32_t *lo_idx, hipStream_t s);
 // radius: count pass (fill == nullptr) then fill pass.  counts/offsets are [query][seg].
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
@@ -64,10 +67,14 @@ hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t 
 
 // ---- select.hip
 // Exact mode: keys are exact distance keys; picks the kout smallest (key, idx).
+// writes results r < kout of query q at [q * out_stride + out_off + r]; when lo_key != nullptr also
+// records the last (key, row) written per query as the next round's lower bound
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
-                                   float *dist_out, hipStream_t s);
+                                   float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
+                                   uint32_t *lo_idx, hipStream_t s);
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
-                                   double *dist_out, hipStream_t s);
+                                   double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
+                                   uint32_t *lo_idx, hipStream_t s);
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).

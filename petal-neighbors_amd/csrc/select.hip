@@ -40,7 +40,10 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
                                                           const uint32_t *__restrict__ cidx,
                                                           const uint32_t *__restrict__ ccnt, size_t nq_pad, int nseg,
                                                           int cap, int kout, uint64_t index_base,
-                                                          uint64_t *__restrict__ idx_out, T *__restrict__ dist_out) {
+                                                          uint64_t *__restrict__ idx_out, T *__restrict__ dist_out,
+                                                          size_t out_stride, size_t out_off,
+                                                          typename KeyOf<T>::type *__restrict__ lo_key,
+                                                          uint32_t *__restrict__ lo_idx) {
     using KeyT = typename KeyOf<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -65,34 +68,43 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         const uint32_t ix = sidx[e];
         const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
-            idx_out[q * kout + r] = index_base + ix;
-            dist_out[q * kout + r] = key_to_dist(k);
+            idx_out[q * out_stride + out_off + r] = index_base + ix;
+            dist_out[q * out_stride + out_off + r] = key_to_dist(k);
+            if (lo_key && r == (uint32_t)kout - 1) {  // next round resumes strictly after this entry
+                lo_key[q] = k;
+                lo_idx[q] = ix;
+            }
         }
     }
     for (uint32_t r = n + lane; r < (uint32_t)kout; r += 64) {  // cannot happen for kout = min(k, n_points)
-        idx_out[q * kout + r] = ~0ull;
-        dist_out[q * kout + r] = key_to_dist(KeyOf<T>::kNaN);
+        idx_out[q * out_stride + out_off + r] = ~0ull;
+        dist_out[q * out_stride + out_off + r] = key_to_dist(KeyOf<T>::kNaN);
     }
 }
 
 template <typename T>
 static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
-                                      T *dist_out, int kp_bound, hipStream_t s) {
+                                      T *dist_out, int kp_bound, size_t out_stride, size_t out_off, void *lo_key,
+                                      uint32_t *lo_idx, hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
-                       index_base, idx_out, dist_out);
+                       index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx);
     return hipGetLastError();
 }
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
-                                   float *dist_out, hipStream_t s) {
-    return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, s);
+                                   float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
+                                   uint32_t *lo_idx, hipStream_t s) {
+    return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
+                                      lo_key, lo_idx, s);
 }
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
-                                   double *dist_out, hipStream_t s) {
-    return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, s);
+                                   double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
+                                   uint32_t *lo_idx, hipStream_t s) {
+    return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
+                                       lo_key, lo_idx, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -109,6 +109,18 @@ def test_exact_engine_vs_oracle(pn, oracle_mod, dtype, n, dim, nq, k):
     _check_knn(pn, oracle_mod, pts, qs, k)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_k_beyond_one_buffer_is_served_in_rounds(pn, oracle_mod, dtype):
+    """k > 960 (one candidate buffer): rounds that resume after the last (distance, index); includes
+    k == n (a full sort of the corpus per query) and heavy ties across a round boundary."""
+    pts = uniform((5000, 6), 123, dtype)
+    qs = uniform((5, 6), 124, dtype)
+    _check_knn(pn, oracle_mod, pts, qs, 2000)
+    _check_knn(pn, oracle_mod, pts[:3000], qs[:2], 3000)
+    ties = np.repeat(uniform((40, 4), 9, dtype), 60, axis=0)  # 40 distinct rows, 60 copies each
+    _check_knn(pn, oracle_mod, ties, qs[:3, :4], 1500)
+
+
 def test_exact_engine_signed_wide_range(pn, oracle_mod):
     rng = np.random.default_rng(3)
     pts = (rng.standard_normal((3000, 20)) * np.exp(rng.uniform(-6, 6, (3000, 1)))).astype(np.float32)
