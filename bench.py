@@ -184,6 +184,18 @@ def main():
         flops_per_launch = 2.0 * n_local * dim * nq  # 2*N*D per query
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
         engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
+        kernel_name = (("mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
+                        else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel")
+        # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same
+        # command (counters cannot be read in-process); the committed summary is used when it describes
+        # this kernel and config on one GPU, else null.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_v2_pmc.json")))
+            if pmc.get("kernel") == kernel_name and pmc.get("config") == args.config and world == 1:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "exact k-NN queries/sec (1M x 128 fp32, k=10)" if args.config == "c2"
                       else f"exact k-NN queries/sec ({n} x {dim} fp32, k={k})",
@@ -194,9 +206,9 @@ def main():
                        "n_points": n, "dim": dim, "n_queries": nq, "k": k, "engine": engine_used,
                        "sharding": f"corpus rows / {world}" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": ("mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
-                                    else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel",
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c2_v2_pmc.json)",
+                         "kernel": kernel_name,
                          "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
                                                   / (PEAK_F32_MFMA_TFLOPS * world), 4)},

@@ -176,12 +176,14 @@ double pn_distance_to_rdistance_f64(double d);
 
 /* ---- row-sharded corpora: merge `n_parts` per-shard results
  * (each nq x k_part, already carrying global indices via PN_OPT_INDEX_BASE and
- * sorted by (distance, index)) into the global top k_out.  Device pointers;
- * parts are laid out [part][query][k_part], as an all-gather leaves them.
- * Slots with index UINT64_MAX are treated as absent. */
+ * sorted by (distance, index)) into the global top k_out.  Device pointers.
+ * Part p's indices start at d_idx_parts + p * idx_part_stride (elements), its
+ * distances at d_dist_parts + p * dist_part_stride, each laid out [query][k_part]
+ * -- so one all-gather of a packed per-rank buffer {idx[nq][k] | dist[nq][k]}
+ * can be merged in place.  Slots with index UINT64_MAX are treated as absent. */
 int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
-                             size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
-                             float *d_dist_out, int device, void *stream);
+                             size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
+                             size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device, void *stream);
 
 /* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
  * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in

@@ -65,7 +65,7 @@ SIGNATURES = {
     "pn_rdistance_to_distance_f64": (C.c_double, [C.c_double]),
     "pn_distance_to_rdistance_f32": (C.c_float, [C.c_float]),
     "pn_distance_to_rdistance_f64": (C.c_double, [C.c_double]),
-    "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
+    "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
 }
 

@@ -881,8 +881,9 @@ extern "C" int pn_pairwise_f64(const double *x, size_t n, size_t cols, ptrdiff_t
 // shard merge + generator
 // ---------------------------------------------------------------------------
 extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
-                                        size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
-                                        float *d_dist_out, int device, void *stream) {
+                                        size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
+                                        size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device,
+                                        void *stream) {
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!d_idx_parts || !d_dist_parts || !d_idx_out || !d_dist_out) return fail(PN_ERR_INVALID, "NULL argument");
     if (n_parts == 0 || k_part == 0) return fail(PN_ERR_INVALID, "empty parts");
@@ -890,8 +891,8 @@ extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float
     PNCHK(check_device(device));
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
-    HIPCHK(launch_merge_topk_f32(d_idx_parts, d_dist_parts, (int)n_parts, (int)nq, (int)k_part, (int)k_out, d_idx_out,
-                                 d_dist_out, (hipStream_t)stream));
+    HIPCHK(launch_merge_topk_f32(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq,
+                                 (int)k_part, (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream));
     return PN_OK;
 }
 

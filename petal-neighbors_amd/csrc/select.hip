@@ -225,7 +225,8 @@ hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n,
 // shard merge: parts laid out [part][query][k_part]; (dist, idx) total order.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restrict__ idx_parts,
-                                                        const float *__restrict__ dist_parts, int n_parts, int nq,
+                                                        const float *__restrict__ dist_parts, int n_parts,
+                                                        size_t idx_part_stride, size_t dist_part_stride, int nq,
                                                         int k_part, int k_out, uint64_t *__restrict__ idx_out,
                                                         float *__restrict__ dist_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -236,10 +237,10 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t part = e / k_part, j = e % k_part;
-        const size_t o = ((size_t)part * nq + q) * k_part + j;
-        const uint64_t ix = idx_parts[o];
+        const size_t o = q * k_part + j;
+        const uint64_t ix = idx_parts[(size_t)part * idx_part_stride + o];
         sidx[e] = ix;
-        skey[e] = (ix == ~0ull) ? KeyOf<float>::kMax : sel_key(dist_parts[o]);
+        skey[e] = (ix == ~0ull) ? KeyOf<float>::kMax : sel_key(dist_parts[(size_t)part * dist_part_stride + o]);
     }
     __syncthreads();
     uint32_t n_valid = 0;
@@ -262,12 +263,13 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     }
 }
 
-hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts, int nq,
-                                 int k_part, int k_out, uint64_t *idx_out, float *dist_out, hipStream_t s) {
+hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
+                                 size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
+                                 uint64_t *idx_out, float *dist_out, hipStream_t s) {
     const size_t sh = (size_t)n_parts * k_part * 12;
     if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts, nq,
-                       k_part, k_out, idx_out, dist_out);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
+                       idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out);
     return hipGetLastError();
 }
 

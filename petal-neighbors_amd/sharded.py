@@ -54,17 +54,40 @@ class HipShardEngine:
         return self.tree.query_radius_batch(queries.cpu().numpy(), r)
 
     def merge(self, idx_parts, dist_parts, k_out: int):
-        """parts: (G, nq, k_part) CUDA tensors -> (nq, k_out)."""
+        """parts: (G, nq, k_part) CUDA tensors (any part stride, rows contiguous) -> (nq, k_out)."""
         import torch
         from . import _lib
         from .errors import check
         g, nq, kp = idx_parts.shape
+        assert idx_parts.stride(1) == kp and idx_parts.stride(2) == 1
+        assert dist_parts.stride(1) == kp and dist_parts.stride(2) == 1
         out_i = torch.empty((nq, k_out), dtype=torch.int64, device=idx_parts.device)
         out_d = torch.empty((nq, k_out), dtype=torch.float32, device=idx_parts.device)
         st = torch.cuda.current_stream(idx_parts.device).cuda_stream
-        check(_lib.lib().pn_merge_topk_device_f32(idx_parts.data_ptr(), dist_parts.data_ptr(), g, nq, kp, k_out,
+        check(_lib.lib().pn_merge_topk_device_f32(idx_parts.data_ptr(), dist_parts.data_ptr(), g,
+                                                  idx_parts.stride(0) if g > 1 else nq * kp,
+                                                  dist_parts.stride(0) if g > 1 else nq * kp, nq, kp, k_out,
                                                   out_i.data_ptr(), out_d.data_ptr(), self.device, C.c_void_p(st)))
         return out_i, out_d
+
+    def pack(self, idx, dst):
+        """One buffer per rank for ONE all-gather: int64 words [idx (nq*k) | dist bits (nq*k/2, padded)]."""
+        import torch
+        nq, kp = idx.shape
+        words = nq * kp + (nq * kp + 1) // 2
+        buf = torch.empty(words, dtype=torch.int64, device=idx.device)
+        buf[: nq * kp] = idx.reshape(-1)
+        buf[nq * kp:].view(torch.float32)[: nq * kp] = dst.reshape(-1)
+        return buf
+
+    def unpack(self, gathered, world, nq, kp):
+        """gathered: (world * words,) int64 -> strided (world, nq, kp) views of indices and distances."""
+        import torch
+        words = nq * kp + (nq * kp + 1) // 2
+        g = gathered.view(world, words)
+        idx = g[:, : nq * kp].unflatten(1, (nq, kp))
+        dst = g[:, nq * kp:].view(torch.float32)[:, : nq * kp].unflatten(1, (nq, kp))
+        return idx, dst
 
     def to_backend(self, a):
         return a
@@ -119,12 +142,12 @@ class ShardedBallTree:
             kl = li.shape[1]
             idx[:, :kl] = li
             dst[:, :kl] = ld
-        g_idx = self.engine.empty((self.world * nq, k_part), torch.int64)
-        g_dst = self.engine.empty((self.world * nq, k_part), torch.float32)
-        # the one exchange step of the path: all-gather of per-shard top-k (RCCL over xGMI)
-        self.dist.all_gather_into_tensor(g_idx, idx, group=self.group)
-        self.dist.all_gather_into_tensor(g_dst, dst, group=self.group)
-        return self.engine.merge(g_idx.view(self.world, nq, k_part), g_dst.view(self.world, nq, k_part), k_out)
+        # the one exchange step of the path: ONE all-gather of the packed per-shard top-k (RCCL over xGMI)
+        mine = self.engine.pack(idx, dst)
+        gathered = self.engine.empty((self.world * mine.numel(),), torch.int64)
+        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        g_idx, g_dst = self.engine.unpack(gathered, self.world, nq, k_part)
+        return self.engine.merge(g_idx, g_dst, k_out)
 
     def query(self, point, k: int):
         i, d = self.query_batch(point.reshape(1, -1), k)

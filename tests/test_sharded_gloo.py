@@ -49,8 +49,8 @@ class OracleShardEngine:
     def merge(self, idx_parts, dist_parts, k_out):
         """(G, nq, kp) -> (nq, k_out) by (distance total order, index); index -1 = absent."""
         g, nq, kp = idx_parts.shape
-        ii = idx_parts.numpy().astype(np.uint64).transpose(1, 0, 2).reshape(nq, g * kp)
-        dd = dist_parts.numpy().transpose(1, 0, 2).reshape(nq, g * kp)
+        ii = idx_parts.contiguous().numpy().astype(np.uint64).transpose(1, 0, 2).reshape(nq, g * kp)
+        dd = dist_parts.contiguous().numpy().transpose(1, 0, 2).reshape(nq, g * kp)
         oi = np.full((nq, k_out), -1, dtype=np.int64)
         od = np.full((nq, k_out), np.nan, dtype=np.float32)
         for a in range(nq):
@@ -63,6 +63,15 @@ class OracleShardEngine:
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype)
+
+    # same packing as the HIP engine (one all-gather per batch)
+    def pack(self, idx, dst):
+        from petal_neighbors_amd.sharded import HipShardEngine
+        return HipShardEngine.pack(self, idx, dst)
+
+    def unpack(self, gathered, world, nq, kp):
+        from petal_neighbors_amd.sharded import HipShardEngine
+        return HipShardEngine.unpack(self, gathered, world, nq, kp)
 
 
 def _free_port():
