@@ -39,6 +39,10 @@ CONFIGS = {
     "c4": (10_000_000, 768, 100_000, 10),      # configs[3] (8 GPUs in BASELINE; fits one here)
     "c5": (100_000_000, 96, 1_000_000, 10),    # configs[4]
     "tiny": (20_000, 128, 512, 10),
+    # reduced-scale shapes of the other BASELINE configs (same D and k, 1M rows, 10k queries)
+    "c3s": (1_000_000, 128, 10_000, 100),
+    "c4s": (1_000_000, 768, 10_000, 10),
+    "c5s": (1_000_000, 96, 10_000, 10),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
@@ -184,7 +188,8 @@ def main():
         flops_per_launch = 2.0 * n_local * dim * nq  # 2*N*D per query
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
         engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
-        kernel_name = (("mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
+        kernel_name = (("mfma_filter_wide_kernel" if dim > 128 else
+                        "mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
                         else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel")
         # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same
         # command (counters cannot be read in-process); the committed summary is used when it describes

@@ -147,7 +147,7 @@ static size_t pick_ld(size_t dim) {
     const size_t set[] = {8, 16, 32, 64, 96, 128};
     for (size_t v : set)
         if (dim <= v) return v;
-    return round_up(dim, kRowAlign);
+    return round_up(dim, 128);  // wide rows are processed in 128-coordinate slabs
 }
 
 static float mfma_alpha(size_t dim) {
@@ -532,6 +532,7 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
         if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
             // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
             use_mfma = mfma_slots(ix, kout, nq_pad) + 64 <= 256;
+            if (ix->ld > 128 && mfma_slots(ix, kout, nq_pad) > 30) use_mfma = false;  // wide rows: LDS-buffer kernel only
             if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
         }
         if (use_mfma)
@@ -555,7 +556,8 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
                     float *d_dist, hipStream_t s) {
     // candidate slots kept per (segment, query)
     const size_t kp = mfma_slots(ix, kout, nq_pad);
-    const bool v2 = kp <= 30 && ix->mfma_structure != 1;  // 64 LDS slots, compaction above 32 in use
+    const bool v2 = kp <= 30 && (ix->mfma_structure != 1 || ix->ld > 128);  // 64 LDS slots, compaction above 32 in use
+    if (!v2 && ix->ld > 128) return fail(PN_ERR_UNSUPPORTED, "wide rows need k' <= 30 on the MFMA path");
     int cap = v2 ? 32 : pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
     // scaled query norms (same kernel as the corpus norms)

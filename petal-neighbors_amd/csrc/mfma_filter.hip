@@ -273,7 +273,7 @@ bool mfma_supported(int dim, size_t ld) {
     if (dim < 1) return false;
     switch (ld) {
         case 8: case 16: case 32: case 64: case 96: case 128: return true;
-        default: return false;
+        default: return ld > 128 && ld % 128 == 0;  // wide rows: slab-accumulating kernel (mfma_filter_v2.hip)
     }
 }
 const char *mfma_kernel_name() { return "mfma_filter_kernel"; }

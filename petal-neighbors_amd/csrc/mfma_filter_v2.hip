@@ -477,6 +477,213 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_v2_kernel(
 #endif
 }
 
+// ===========================================================================
+// WIDE rows (D > 128, row length a multiple of 128): same partition, same LDS candidate buffers,
+// but a tile's bound is accumulated over D/128 "slabs" of 64 rows x 128 coordinates.  Slabs form
+// one linear LDS-DMA pipeline across tiles (slab s+1 lands while slab s feeds the matrix pipe);
+// the B operand (this wave's 32 queries, 128 coordinates = 64 VGPRs) is re-read from L2 once per
+// slab into the other of two register sets while the current one is in use.  The filter of a tile
+// (~2 x 80 VALU ops) runs unoverlapped after its last slab: < 2 % of a tile's D/128 x 8320 MFMA
+// cycles.  Algorithmic work is unchanged: 2*D flop per pair, f32 MFMA roof.
+// ===========================================================================
+__device__ __forceinline__ void wide_load_b(const float *__restrict__ qrow, float (&b)[64]) {
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(qrow + 8 * kg);
+        b[4 * kg + 0] = -2.0f * v.x; b[4 * kg + 1] = -2.0f * v.y;
+        b[4 * kg + 2] = -2.0f * v.z; b[4 * kg + 3] = -2.0f * v.w;
+    }
+}
+
+__device__ __forceinline__ void wide_chain(const float *trow, const int (&foff)[16], const float (&b)[64], f32x16 &w) {
+    f32x4 a = *reinterpret_cast<const f32x4 *>(trow + foff[0]);
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+        f32x4 nx = a;
+        if (kg + 1 < 16) nx = *reinterpret_cast<const f32x4 *>(trow + foff[kg + 1]);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * kg + 0], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * kg + 1], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * kg + 2], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * kg + 3], w, 0, 0, 0);
+        a = nx;
+    }
+}
+
+// LDS-DMA of slab (tile rt, chunk c): 64 rows x 128 floats taken from rows of length ldp
+__device__ __forceinline__ void wide_dma_slab(const float *__restrict__ P, size_t ldp, float *tiles, uint32_t rt, int c,
+                                              int buf, int wave, int lane) {
+    const char *src = reinterpret_cast<const char *>(P) + ((size_t)rt * kV2P * ldp + (size_t)c * 128) * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = wv * 8 + i;
+        const int row = g * 2 + lane / 32;
+        const int pos = lane % 32;
+        const int chunk = pos ^ (row & 15);
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + (size_t)row * ldp * 4 + chunk * 16),
+                                         (lds_void *)(tiles + buf * kV2P * 128 + g * 256), 16, 0, 0);
+    }
+}
+
+// one slab: DMA + B prefetch for the next slab, two 64-MFMA chains, (last chunk) norm + filter, barrier
+__device__ __forceinline__ void wide_step(const float *__restrict__ P, const float *__restrict__ pnorm, size_t ldp,
+                                          const float *__restrict__ qbase, float *tiles, float *pnl, uint32_t *cand_k,
+                                          uint32_t *cand_i, uint32_t *taus_w, uint32_t *cnts_w, uint32_t *ckq,
+                                          uint32_t *ciq, uint32_t *cnt_q, uint32_t *tau_q, const int (&foff)[16],
+                                          float bn, float &tau, const float (&bcur)[64], float (&bnext)[64],
+                                          uint32_t s, uint32_t total, uint32_t rt0, int nc, f32x16 &acc0, f32x16 &acc1,
+                                          uint32_t kp, int wave, int lane, int jq, int h) {
+    const uint32_t rt = rt0 + s / nc;
+    const int c = (int)(s % nc);
+    const int cur = (int)(s & 1);
+    if (s + 1 < total) {
+        const uint32_t rtn = rt0 + (s + 1) / nc;
+        const int cn = (int)((s + 1) % nc);
+        wide_dma_slab(P, ldp, tiles, rtn, cn, cur ^ 1, wave, lane);
+        if (cn == 0 && __builtin_amdgcn_readfirstlane(wave) == 0)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pnorm + (size_t)rtn * kV2P + lane),
+                                             (lds_void *)(pnl + (rtn & 1) * kV2P), 4, 0, 0);
+        wide_load_b(qbase + (size_t)cn * 128, bnext);
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    }
+    const float *trow = tiles + cur * kV2P * 128 + jq * 128;
+    wide_chain(trow, foff, bcur, acc0);
+    wide_chain(trow + 32 * 128, foff, bcur, acc1);
+    if (c == nc - 1) {
+        const float an0 = h ? 1.0f : pnl[(rt & 1) * kV2P + jq];
+        const float an1 = h ? 1.0f : pnl[(rt & 1) * kV2P + 32 + jq];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, acc1, 0, 0, 0);
+        float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { m0 = fminf(m0, acc0[r]); m1 = fminf(m1, acc1[r]); }
+        if (__any(m0 < tau)) {
+            append_block(acc0, tau, rt * kV2P, h, ckq, ciq, cnt_q);
+            lds_fence();
+            const uint32_t cq = *cnt_q;
+            unsigned long long need = __ballot(h == 0 && cq > kV2Cap - 32);
+            if (need) {
+                do {
+                    const int j = __builtin_ctzll(need);
+                    need &= need - 1;
+                    compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
+                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j]);
+                } while (need);
+                tau = s2f(*tau_q);
+            }
+        }
+        if (__any(m1 < tau)) {
+            append_block(acc1, tau, rt * kV2P + 32, h, ckq, ciq, cnt_q);
+            lds_fence();
+            const uint32_t cq = *cnt_q;
+            unsigned long long need = __ballot(h == 0 && cq > kV2Cap - 32);
+            if (need) {
+                do {
+                    const int j = __builtin_ctzll(need);
+                    need &= need - 1;
+                    compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
+                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j]);
+                } while (need);
+                tau = s2f(*tau_q);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 1) void mfma_filter_wide_kernel(
+    const float *__restrict__ P, const float *__restrict__ pnorm, uint32_t n_tiles, const float *__restrict__ Q,
+    const float *__restrict__ qnorm, uint32_t q_tiles, uint32_t kp, int nc, size_t ldp, uint32_t *__restrict__ ckey,
+    uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *tiles = reinterpret_cast<float *>(smem_raw);                   // [2][64][128]
+    float *pnl = tiles + 2 * kV2P * 128;                                  // [2][64]
+    uint32_t *cand_k = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);      // [128][64]
+    uint32_t *cand_i = cand_k + kV2Q * kV2Cap;
+    uint32_t *taus = cand_i + kV2Q * kV2Cap;
+    uint32_t *cnts = taus + kV2Q;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jq = lane & 31, h = lane >> 5;
+    const int ql = wave * 32 + jq;
+    uint32_t *ckq = cand_k + ql * kV2Cap, *ciq = cand_i + ql * kV2Cap;
+    uint32_t *cnt_q = cnts + ql, *tau_q = taus + ql;
+    uint32_t *taus_w = taus + wave * 32, *cnts_w = cnts + wave * 32;
+    int foff[16];
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) foff[kg] = 4 * ((2 * kg + h) ^ (jq & 15));
+
+    const unsigned long long U = (unsigned long long)q_tiles * n_tiles;
+    const unsigned long long W = gridDim.x, w = blockIdx.x;
+    unsigned long long u0 = w * U / W;
+    const unsigned long long u1 = (w + 1) * U / W;
+    while (u0 < u1) {
+        const uint32_t qt = (uint32_t)(u0 / n_tiles);
+        const uint32_t rt0 = (uint32_t)(u0 % n_tiles);
+        const unsigned long long q_end = (unsigned long long)(qt + 1) * n_tiles;
+        const unsigned long long run_end = u1 < q_end ? u1 : q_end;
+        const uint32_t rt1 = rt0 + (uint32_t)(run_end - u0);
+        unsigned long long wf = ((unsigned long long)qt * n_tiles) * W / U;
+        while ((wf + 1) * U / W <= (unsigned long long)qt * n_tiles) ++wf;
+        while (wf > 0 && wf * U / W > (unsigned long long)qt * n_tiles) --wf;
+        const uint32_t seg = (uint32_t)(w - wf);
+        const size_t q0 = (size_t)qt * kV2Q + (size_t)wave * 32;
+
+        if (h == 0) { *tau_q = 0xFF800000u; *cnt_q = 0; }
+        const float *qbase = Q + (q0 + jq) * ldp + 4 * h;
+        const float bn = h ? qnorm[q0 + jq] : 1.0f;
+        float tau = __uint_as_float(0x7F800000u);
+        float bA[64], bB[64];
+        const uint32_t total = (rt1 - rt0) * (uint32_t)nc;
+
+        __syncthreads();
+        wide_dma_slab(P, ldp, tiles, rt0, 0, 0, wave, lane);
+        if (__builtin_amdgcn_readfirstlane(wave) == 0)
+            __builtin_amdgcn_global_load_lds((glb_void *)(pnorm + (size_t)rt0 * kV2P + lane),
+                                             (lds_void *)(pnl + (rt0 & 1) * kV2P), 4, 0, 0);
+        wide_load_b(qbase, bA);
+        __syncthreads();
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        for (uint32_t s = 0; s < total; s += 2) {
+            wide_step(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, foff, bn,
+                      tau, bA, bB, s, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
+            if (s + 1 < total)
+                wide_step(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, foff,
+                          bn, tau, bB, bA, s + 1, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
+        }
+
+        {  // flush this run
+            const uint32_t c = *cnt_q;
+            unsigned long long need = __ballot(h == 0 && c > kp);
+            while (need) {
+                const int j = __builtin_ctzll(need);
+                need &= need - 1;
+                compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
+                            (uint32_t)__builtin_amdgcn_readlane((int)c, j), kp, lane, &taus_w[j], &cnts_w[j]);
+            }
+            lds_fence();
+            const size_t gq = (size_t)seg * nq_pad + q0;
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t cj = cnts_w[j];
+                if ((uint32_t)lane < cj) {
+                    ckey[(gq + j) * kV2Keep + lane] = cand_k[(wave * 32 + j) * kV2Cap + lane];
+                    cidx[(gq + j) * kV2Keep + lane] = cand_i[(wave * 32 + j) * kV2Cap + lane];
+                }
+            }
+            if (lane < 32) {
+                ccnt[gq + lane] = cnts_w[lane];
+                ctau[gq + lane] = taus_w[lane];
+            }
+        }
+        u0 = run_end;
+    }
+}
+
 #ifdef PN_DIAG_COUNT
 extern "C" int pn_debug_read(unsigned long long *out, int reset) {
     unsigned long long z[8] = {0};
@@ -517,6 +724,22 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
     const uint32_t n_tiles = (uint32_t)((n + kV2P - 1) / kV2P);
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kV2Q);
     if (cb.nseg < mfma_v2_max_segments(q_tiles, n_wg)) return hipErrorInvalidValue;
+    if (ldp > 128) {
+        if (ldp % 128) return hipErrorInvalidValue;
+        const size_t sh = (size_t)(2 * kV2P * 128 + 2 * kV2P) * sizeof(float) +
+                          (size_t)(2 * kV2Q * kV2Cap + 2 * kV2Q) * sizeof(uint32_t);
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_filter_wide_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(mfma_filter_wide_kernel, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm,
+                           q_tiles, (uint32_t)kp, (int)(ldp / 128), ldp, static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt,
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad);
+        return hipGetLastError();
+    }
     switch (ldp) {
         case 8: return launch_v2<1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
         case 16: return launch_v2<2>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);

@@ -236,6 +236,17 @@ def test_mfma_engine_vs_oracle(pn, oracle_mod, n, dim, nq, k):
     assert st["candidates"] >= nq * min(k, n)
 
 
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 768, 200, 10), (9000, 200, 150, 10), (5000, 129, 70, 5),
+                                        (3000, 1024, 40, 20), (70000, 256, 300, 1)])
+def test_mfma_engine_wide_rows(pn, oracle_mod, n, dim, nq, k):
+    """D > 128 (BASELINE config 4 is D = 768): slab-accumulating MFMA filter kernel."""
+    pts = uniform((n, dim), 0xD1CE + n + dim, np.float32)
+    qs = np.concatenate([pts[: nq // 3], uniform((nq - nq // 3, dim), 0xFACE + n, np.float32)])
+    tree = _check_knn(pn, oracle_mod, pts, qs, k, "mfma")
+    assert tree.stats()["candidates"] >= nq * k
+    _check_knn(pn, oracle_mod, pts[:4000], qs[:20], k, "auto")
+
+
 def test_mfma_engine_gaussian_clusters_and_scales(pn, oracle_mod):
     rng = np.random.default_rng(11)
     centers = rng.standard_normal((20, 48)) * 10
