@@ -741,6 +741,87 @@ template <> struct RadOps<double> {
     }
 };
 
+// query_radius through the MFMA filter (f32, D <= 128, finite positive r).  *done = false means the
+// caller must run the exact two-pass engine instead (a survivor list overflowed, or a query norm is not
+// finite): correctness never depends on this path being taken.
+static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+                       uint64_t **idx_out, bool *done, hipStream_t s) {
+    *done = false;
+    const uint32_t cap = 32;
+    const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
+    size_t n_wg = (size_t)ix->n_cu * 2;
+    size_t cap_wg = q_tiles * 32;
+    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    if (by_work < cap_wg) cap_wg = by_work;
+    if (cap_wg < 1) cap_wg = 1;
+    if (n_wg > cap_wg) n_wg = cap_wg;
+    const int nseg = mfma_v2_max_segments(q_tiles, (int)n_wg);
+    const size_t cells = (size_t)nseg * nq_pad;
+    const size_t kept_stride = (size_t)nseg * cap;
+    // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24), rounded up; the kernel tests L < succ(tau_r)
+    const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
+    float tf = (float)t;
+    if ((double)tf < t) tf = nextafterf(tf, INFINITY);
+    if (!(tf < INFINITY)) return PN_OK;  // r^2 overflows f32: let the exact engine decide
+    const float tau_excl = nextafterf(tf, INFINITY);
+
+    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
+    PNCHK(ix->w_misc.ensure(64));
+    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_idx.ensure(cells * cap * sizeof(uint32_t)));
+    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));  // kept rows per query
+    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));           // kept counts
+    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] non-finite query norms
+    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
+                                d_misc + 1, s));
+    HIPCHK(launch_mfma_radius_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ix->w_qnorm.p,
+                                  nq_pad, tau_excl, cap, (uint32_t *)ix->w_cnt.p, (uint32_t *)ix->w_idx.p, (int)n_wg, s));
+    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p, nq_pad, nseg, cap,
+                                   (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
+                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, s));
+    uint32_t h_misc[2] = {0, 0};
+    std::vector<uint32_t> h_n(nq);
+    HIPCHK(hipMemcpyAsync(h_misc, d_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_n.data(), ix->w_flags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_misc[0] || h_misc[1]) return PN_OK;  // not done: exact engine
+    std::vector<uint64_t> h_off(nq + 1);
+    uint64_t run = 0;
+    for (size_t a = 0; a < nq; ++a) {
+        h_off[a] = run;
+        run += h_n[a];
+    }
+    h_off[nq] = run;
+    uint64_t *h_out = (uint64_t *)malloc((run ? run : 1) * sizeof(uint64_t));
+    if (!h_out) return fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)run);
+    if (run) {
+        uint64_t *d_off = nullptr, *d_out = nullptr;
+        int rc = PN_OK;
+        if (hipMalloc((void **)&d_off, (nq + 1) * 8) != hipSuccess || hipMalloc((void **)&d_out, run * 8) != hipSuccess)
+            rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed");
+        if (rc == PN_OK &&
+            (hipMemcpyAsync(d_off, h_off.data(), (nq + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+             launch_radius_gather((const uint32_t *)ix->w_keys.p, (const uint32_t *)ix->w_flags.p, d_off, (int)nq,
+                                  kept_stride, ix->index_base, d_out, s) != hipSuccess ||
+             hipMemcpyAsync(h_out, d_out, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+             hipStreamSynchronize(s) != hipSuccess))
+            rc = fail(PN_ERR_DEVICE, "radius gather failed: %s", hipGetErrorString(hipGetLastError()));
+        if (d_off) (void)hipFree(d_off);
+        if (d_out) (void)hipFree(d_out);
+        if (rc != PN_OK) {
+            free(h_out);
+            return rc;
+        }
+    }
+    memcpy(offsets, h_off.data(), (nq + 1) * sizeof(uint64_t));
+    *idx_out = h_out;
+    ix->stats.radius_results += run;
+    *done = true;
+    return PN_OK;
+}
+
 template <typename T>
 static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, T radius,
                             uint64_t *offsets, uint64_t **idx_out) {
@@ -772,6 +853,16 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
         if (Ops<T>::pack(d_q, nq, dim_eff, q_cols ? q_cols : 1, Qp, nq_pad, ix->ld, s) != hipSuccess) {
             rc = fail(PN_ERR_DEVICE, "pack failed");
             break;
+        }
+        if constexpr (sizeof(T) == 4) {
+            const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
+            if (ix->mfma_ok && ix->ld <= 128 && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && finite_pos &&
+                (ix->engine == PN_ENGINE_MFMA || (ix->n >= 4096 && ix->dim >= 8))) {
+                bool done = false;
+                rc = radius_mfma(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
+                if (rc != PN_OK || done) break;
+                ix->stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
+            }
         }
         const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, 1, ix->opt_segments, 4096, 64);
         const size_t cells = nq * (size_t)pl.nseg;

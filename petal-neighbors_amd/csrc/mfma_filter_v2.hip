@@ -684,6 +684,200 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_wide_kernel(
     }
 }
 
+// ===========================================================================
+// query_radius on the matrix cores (D <= 128): the same lower bound L against ONE fixed threshold
+//   tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24), rounded up.
+// L > tau_r  =>  |q-p|^2 > tau_r  =>  the reference's f32 fold s_ref >= r^2  =>  sqrt(s_ref) >= r,
+// so a row is dropped only when the reference's strict test `dist < r` (src/ball_tree.rs:277)
+// would drop it too.  Survivors (rare for sparse results) are appended to per-(segment, query)
+// lists in HBM with a global atomic; a list that overflows its capacity sends the batch to the
+// exact two-pass engine.  No threshold state, so no LDS buffers: 2 workgroups per CU.
+// ===========================================================================
+template <int NKG>
+__device__ __forceinline__ void plain_chain(const float *trow, const int (&foff)[NKG], float an, float bn,
+                                            const float (&b)[4 * NKG], f32x16 &w) {
+    f32x4 a = *reinterpret_cast<const f32x4 *>(trow + foff[0]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = 0.0f;
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+        f32x4 nx = a;
+        if (kg + 1 < NKG) nx = *reinterpret_cast<const f32x4 *>(trow + foff[kg + 1]);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * kg + 0], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * kg + 1], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * kg + 2], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * kg + 3], w, 0, 0, 0);
+        a = nx;
+    }
+    w = __builtin_amdgcn_mfma_f32_32x32x2f32(an, bn, w, 0, 0, 0);
+}
+
+__device__ __forceinline__ void radius_append(const f32x16 &acc, float tau_excl, uint32_t row0, int h,
+                                              uint32_t *__restrict__ rcnt, uint32_t *__restrict__ ridx, size_t cell,
+                                              uint32_t cap) {
+    uint32_t mask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mask |= (acc[r] < tau_excl ? 1u : 0u) << r;
+    const uint32_t npass = (uint32_t)__popc(mask);
+    if (npass) {
+        uint32_t o = atomicAdd(&rcnt[cell], npass);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (mask & (1u << r)) {
+                if (o < cap) ridx[cell * cap + o] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                ++o;
+            }
+        }
+    }
+}
+
+template <int NKG>
+__global__ __launch_bounds__(256, 2) void mfma_radius_kernel(
+    const float *__restrict__ P, const float *__restrict__ pnorm, uint32_t n_tiles, const float *__restrict__ Q,
+    const float *__restrict__ qnorm, uint32_t q_tiles, float tau_excl, uint32_t cap, uint32_t *__restrict__ rcnt,
+    uint32_t *__restrict__ ridx, size_t nq_pad) {
+    constexpr int LD = V2Ctx<NKG>::LD, STR = V2Ctx<NKG>::STR, CHUNKS = V2Ctx<NKG>::CHUNKS, NLD = V2Ctx<NKG>::NLD;
+    constexpr bool GLDS = V2Ctx<NKG>::GLDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *tiles = reinterpret_cast<float *>(smem_raw);  // [2][64][STR]
+    float *pnl = tiles + 2 * kV2P * STR;                 // [2][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jq = lane & 31, h = lane >> 5;
+    const uint32_t lane_off = (uint32_t)tid * 16u;
+    int foff[NKG];
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) foff[kg] = 4 * (GLDS ? ((2 * kg + h) ^ (jq & 15)) : (2 * kg + h));
+
+    const unsigned long long U = (unsigned long long)q_tiles * n_tiles;
+    const unsigned long long W = gridDim.x, w = blockIdx.x;
+    unsigned long long u0 = w * U / W;
+    const unsigned long long u1 = (w + 1) * U / W;
+    while (u0 < u1) {
+        const uint32_t qt = (uint32_t)(u0 / n_tiles);
+        const uint32_t rt0 = (uint32_t)(u0 % n_tiles);
+        const unsigned long long q_end = (unsigned long long)(qt + 1) * n_tiles;
+        const unsigned long long run_end = u1 < q_end ? u1 : q_end;
+        const uint32_t rt1 = rt0 + (uint32_t)(run_end - u0);
+        unsigned long long wf = ((unsigned long long)qt * n_tiles) * W / U;
+        while ((wf + 1) * U / W <= (unsigned long long)qt * n_tiles) ++wf;
+        while (wf > 0 && wf * U / W > (unsigned long long)qt * n_tiles) --wf;
+        const uint32_t seg = (uint32_t)(w - wf);
+        const size_t q0 = (size_t)qt * kV2Q + (size_t)wave * 32;
+        const size_t cell = (size_t)seg * nq_pad + q0 + jq;
+
+        float b[4 * NKG];
+        {
+            const float *qrow = Q + (q0 + jq) * LD + 4 * h;
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(qrow + 8 * kg);
+                b[4 * kg + 0] = -2.0f * v.x; b[4 * kg + 1] = -2.0f * v.y;
+                b[4 * kg + 2] = -2.0f * v.z; b[4 * kg + 3] = -2.0f * v.w;
+            }
+        }
+        const float bn = h ? qnorm[q0 + jq] : 1.0f;
+        f32x4 st[NLD];
+        float stn = 0.0f;
+        __syncthreads();
+        if constexpr (GLDS) {
+            v2_dma_tile<NKG>(P, pnorm, tiles, pnl, rt0, 0, wave, lane);
+        } else {
+            const char *src_ = reinterpret_cast<const char *>(P) + (size_t)rt0 * (size_t)(kV2P * LD * 4);
+#pragma unroll
+            for (int i_ = 0; i_ < NLD; ++i_)
+                if (CHUNKS % 256 == 0 || tid + 256 * i_ < CHUNKS)
+                    st[i_] = *reinterpret_cast<const f32x4 *>(src_ + (lane_off + 4096u * i_));
+            stn = pnorm[(size_t)rt0 * kV2P + (tid & 63)];
+#pragma unroll
+            for (int i_ = 0; i_ < NLD; ++i_) {
+                const int c_ = tid + 256 * i_;
+                if (CHUNKS % 256 == 0 || c_ < CHUNKS)
+                    *reinterpret_cast<f32x4 *>(tiles + (c_ / (LD / 4)) * STR + 4 * (c_ % (LD / 4))) = st[i_];
+            }
+            if (tid < kV2P) pnl[tid] = stn;
+        }
+        __syncthreads();
+
+        int cur = 0;
+        for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1) {
+            const bool more = rt + 1 < rt1;
+            if (more) {
+                if constexpr (GLDS) {
+                    v2_dma_tile<NKG>(P, pnorm, tiles, pnl, rt + 1, cur ^ 1, wave, lane);
+                } else {
+                    const char *src_ = reinterpret_cast<const char *>(P) + (size_t)(rt + 1) * (size_t)(kV2P * LD * 4);
+#pragma unroll
+                    for (int i_ = 0; i_ < NLD; ++i_)
+                        if (CHUNKS % 256 == 0 || tid + 256 * i_ < CHUNKS)
+                            st[i_] = *reinterpret_cast<const f32x4 *>(src_ + (lane_off + 4096u * i_));
+                    stn = pnorm[(size_t)(rt + 1) * kV2P + (tid & 63)];
+                }
+            }
+            const float *trow = tiles + cur * kV2P * STR + jq * STR;
+            const float an0 = h ? 1.0f : pnl[cur * kV2P + jq];
+            const float an1 = h ? 1.0f : pnl[cur * kV2P + 32 + jq];
+            f32x16 acc0, acc1;
+            plain_chain<NKG>(trow, foff, an0, bn, b, acc0);
+            plain_chain<NKG>(trow + 32 * STR, foff, an1, bn, b, acc1);
+            float m = fminf(acc0[0], acc1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fminf(m, fminf(acc0[r], acc1[r]));
+            if (!GLDS && more) {
+                float *dst_ = tiles + (cur ^ 1) * kV2P * STR;
+#pragma unroll
+                for (int i_ = 0; i_ < NLD; ++i_) {
+                    const int c_ = tid + 256 * i_;
+                    if (CHUNKS % 256 == 0 || c_ < CHUNKS)
+                        *reinterpret_cast<f32x4 *>(dst_ + (c_ / (LD / 4)) * STR + 4 * (c_ % (LD / 4))) = st[i_];
+                }
+                if (tid < kV2P) pnl[(cur ^ 1) * kV2P + tid] = stn;
+            }
+            if (__any(m < tau_excl)) {
+                radius_append(acc0, tau_excl, rt * kV2P, h, rcnt, ridx, cell, cap);
+                radius_append(acc1, tau_excl, rt * kV2P + 32, h, rcnt, ridx, cell, cap);
+                __builtin_amdgcn_s_waitcnt(0x0070);  // drain the list stores (see mfma_filter.hip)
+            }
+            __syncthreads();
+        }
+        u0 = run_end;
+    }
+}
+
+template <int NKG>
+static hipError_t launch_radius_t(const float *P, const float *pnorm, uint32_t n_tiles, const float *Q,
+                                  const float *qnorm, uint32_t q_tiles, float tau_excl, uint32_t cap, uint32_t *rcnt,
+                                  uint32_t *ridx, size_t nq_pad, int n_wg, hipStream_t s) {
+    const size_t sh = (size_t)(2 * kV2P * V2Ctx<NKG>::STR + 2 * kV2P) * sizeof(float);
+    auto kern = mfma_radius_kernel<NKG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap,
+                       rcnt, ridx, nq_pad);
+    return hipGetLastError();
+}
+
+// rcnt [nseg][nq_pad] must be zeroed; ridx [nseg][nq_pad][cap]; nseg >= mfma_v2_max_segments(q_tiles, n_wg)
+hipError_t launch_mfma_radius_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
+                                  const float *qnorm, size_t nq_pad, float tau_excl, uint32_t cap, uint32_t *rcnt,
+                                  uint32_t *ridx, int n_wg, hipStream_t s) {
+    const uint32_t n_tiles = (uint32_t)((n + kV2P - 1) / kV2P);
+    const uint32_t q_tiles = (uint32_t)(nq_pad / kV2Q);
+    switch (ldp) {
+        case 8: return launch_radius_t<1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        case 16: return launch_radius_t<2>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        case 32: return launch_radius_t<4>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        case 64: return launch_radius_t<8>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        case 96: return launch_radius_t<12>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        case 128: return launch_radius_t<16>(P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap, rcnt, ridx, nq_pad, n_wg, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 #ifdef PN_DIAG_COUNT
 extern "C" int pn_debug_read(unsigned long long *out, int reset) {
     unsigned long long z[8] = {0};

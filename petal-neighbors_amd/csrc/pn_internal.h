@@ -121,4 +121,16 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
                                      const float *qnorm, size_t ldq, int kp, const CandBuf &cb, int n_wg,
                                      hipStream_t s);
 
+// radius filter (mfma_filter_v2.hip) + exact check / ascending-row ordering of its survivors (select.hip)
+hipError_t launch_mfma_radius_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
+                                  const float *qnorm, size_t nq_pad, float tau_excl, uint32_t cap, uint32_t *rcnt,
+                                  uint32_t *ridx, int n_wg, hipStream_t s);
+// per query: exact distance of every listed row, keep dist < r, order by row; kept[q][*], nkept[q]; *overflow += 1
+// when some list of the query exceeded `cap`
+hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
+                                   const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, hipStream_t s);
+hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
+                                size_t kept_stride, uint64_t index_base, uint64_t *out, hipStream_t s);
+
 }  // namespace pn

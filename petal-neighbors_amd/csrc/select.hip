@@ -222,6 +222,75 @@ hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n,
 }
 
 // ---------------------------------------------------------------------------
+// radius: exact check of the filter's survivors.  block = 64 threads = one query.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__restrict__ rcnt,
+                                                          const uint32_t *__restrict__ ridx, size_t nq_pad, int nseg,
+                                                          uint32_t cap, const float *__restrict__ P, size_t ldp,
+                                                          const float *__restrict__ Q, int dim, float r,
+                                                          uint32_t *__restrict__ kept, uint32_t *__restrict__ nkept,
+                                                          uint32_t *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *srow = reinterpret_cast<uint32_t *>(smem);  // rows that pass the exact test
+    __shared__ uint32_t n_pass;
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    if (lane == 0) n_pass = 0;
+    __syncthreads();
+    const float *qrow = Q + q * ldp;
+    bool over = false;
+    for (int s = 0; s < nseg; ++s) {
+        uint32_t c = rcnt[(size_t)s * nq_pad + q];
+        if (c > cap) { over = true; c = cap; }
+        const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
+        for (uint32_t e = lane; e < c; e += 64) {
+            const uint32_t row = ridx[base + e];
+            const float d = exact_distance_f32(qrow, P + (size_t)row * ldp, dim);
+            if (d < r) srow[atomicAdd(&n_pass, 1u)] = row;  // strict '<' (src/ball_tree.rs:277); NaN never matches
+        }
+    }
+    __syncthreads();
+    const uint32_t n = n_pass;
+    const size_t stride = (size_t)nseg * cap;
+    for (uint32_t e = lane; e < n; e += 64) {  // ascending row order by rank counting (rows are unique)
+        const uint32_t row = srow[e];
+        uint32_t rk = 0;
+        for (uint32_t j = 0; j < n; ++j) rk += srow[j] < row ? 1u : 0u;
+        kept[q * stride + rk] = row;
+    }
+    if (lane == 0) {
+        nkept[q] = n;
+        if (over) atomicAdd(overflow, 1u);
+    }
+}
+
+hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
+                                   const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, hipStream_t s) {
+    const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q,
+                       dim, r, kept, nkept, overflow);
+    return hipGetLastError();
+}
+
+__global__ void radius_gather_kernel(const uint32_t *__restrict__ kept, const uint32_t *__restrict__ nkept,
+                                     const uint64_t *__restrict__ offsets, size_t kept_stride, uint64_t index_base,
+                                     uint64_t *__restrict__ out) {
+    const size_t q = blockIdx.x;
+    const uint32_t n = nkept[q];
+    const uint64_t o = offsets[q];
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) out[o + e] = index_base + kept[q * kept_stride + e];
+}
+hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
+                                size_t kept_stride, uint64_t index_base, uint64_t *out, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(radius_gather_kernel, dim3((unsigned)nq), dim3(64), 0, s, kept, nkept, offsets, kept_stride,
+                       index_base, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // shard merge: parts laid out [part][query][k_part]; (dist, idx) total order.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restrict__ idx_parts,

@@ -344,6 +344,33 @@ def test_query_radius_vs_oracle(pn, oracle_mod, dtype):
     assert list(t.query_radius(np.array([3.0], dtype=dtype), 1.0)) == [2]
 
 
+@pytest.mark.parametrize("engine", ["mfma", "auto", "exact"])
+def test_query_radius_mfma_filter(pn, oracle_mod, engine):
+    """query_radius through the MFMA filter: sparse results stay on it, dense results overflow the
+    survivor lists and are re-run exactly; boundary radii (r == an exact distance) keep the strict '<'."""
+    for n, dim in ((20000, 128), (9000, 96), (6000, 16), (5000, 3)):
+        pts = uniform((n, dim), 51 + n, np.float32)
+        qs = np.concatenate([pts[:10], uniform((23, dim), 52 + n, np.float32)])
+        tree = pn.BallTree.euclidean(pts)
+        tree.set_engine(engine)
+        _, d = oracle_mod.brute_knn(pts, qs, 40)
+        radii = [float(np.median(d[:, 3])), float(d[12, 5]), float(d[:, 30].max()) * 1.01, 1e-6, 0.0, -1.0,
+                 float("inf"), float("nan")]
+        for r in radii:
+            off, idx = tree.query_radius_batch(qs, r)
+            assert off[0] == 0 and off[-1] == len(idx)
+            for a in range(len(qs)):
+                want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+                assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), (n, dim, r, a, engine)
+    # exact boundary: r equal to a stored distance must exclude that row
+    pts = uniform((8000, 64), 77, np.float32)
+    q = uniform((64,), 78, np.float32)
+    tree = pn.BallTree.euclidean(pts).set_engine(engine)
+    i5, d5 = tree.query(q, 5)
+    got = tree.query_radius(q, float(d5[4]))
+    assert list(got) == sorted(int(i) for i in i5[:4])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_pairwise_vs_oracle(pn, oracle_mod, dtype):
     for n, dim in ((1, 3), (2, 2), (65, 7), (300, 128), (130, 131)):
