@@ -71,7 +71,8 @@ enum {
     PN_OPT_INDEX_BASE = 3,  /* added to every returned index (row-sharded corpora) */
     PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream */
     PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
-    PN_OPT_MFMA_STRUCTURE = 6 /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent balanced partition */
+    PN_OPT_MFMA_STRUCTURE = 6 /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
+                                 buffers, 1 workgroup/CU; 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU */
 };
 
 typedef struct pn_index pn_index;

@@ -21,5 +21,6 @@ from . import distance  # noqa: E402
 from .ball_tree import BallTree  # noqa: E402
 from .errors import ArrayError, PetalError  # noqa: E402
 from .sharded import ShardedBallTree  # noqa: E402
+from .vantage_point_tree import VantagePointTree  # noqa: E402
 
-__all__ = ["BallTree", "ShardedBallTree", "ArrayError", "PetalError", "LibraryMissing", "distance"]
+__all__ = ["BallTree", "VantagePointTree", "ShardedBallTree", "ArrayError", "PetalError", "LibraryMissing", "distance"]

@@ -346,7 +346,7 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             ix->filter_slots = (int)value;
             return PN_OK;
         case PN_OPT_MFMA_STRUCTURE:
-            if (value < 0 || value > 2) return fail(PN_ERR_INVALID, "bad structure");
+            if (value < 0 || value > 3) return fail(PN_ERR_INVALID, "bad structure");
             ix->mfma_structure = (int)value;
             return PN_OK;
         default: return fail(PN_ERR_INVALID, "unknown option %d", option);
@@ -494,7 +494,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
 static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
     if (ix->filter_slots > 0) return (size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots;
     const size_t q_tiles = nq_pad / 128;
-    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu && kout + 2 <= 30;
+    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu && kout + 2 <= 30;  // (>= 3 segments even with one workgroup per CU)
     if (many_segments) return kout + 2;
     return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
@@ -570,7 +570,9 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
                                 d_nflag + 1, s));
     MfmaPlan plan{};
-    int n_wg = ix->n_cu;
+    // structure 3: persistent partition with HBM candidate buffers and two workgroups per CU
+    const bool two_per_cu = v2 && (ix->mfma_structure == 3 || ix->mfma_structure == 0) && ix->ld <= 128;
+    int n_wg = two_per_cu ? 2 * ix->n_cu : ix->n_cu;
     if (v2) {
         // at most ~32 workgroups per query tile and at least ~32 row tiles per workgroup
         const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
@@ -601,9 +603,14 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     }
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    uint32_t *gcand = nullptr;
+    if (two_per_cu) {
+        PNCHK(ix->w_sel.ensure(mfma_v2_gcand_bytes(n_wg)));
+        gcand = (uint32_t *)ix->w_sel.p;
+    }
     if (v2)
         HIPCHK(launch_mfma_filter_v2_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp,
-                                         (const float *)ix->w_qnorm.p, ix->ld, (int)kp, cb, n_wg, s));
+                                         (const float *)ix->w_qnorm.p, ix->ld, (int)kp, cb, n_wg, gcand, s));
     else
         HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld,
                                       Qp, (const float *)ix->w_qnorm.p, (int)nq, ix->ld, plan, cb, s));

@@ -64,10 +64,21 @@ constexpr uint32_t kV2Keep = 32;  // slots per (segment, query) handed to the se
 // executes a wave's operations in order, so only the compiler must be held back.  Unlike a
 // workgroup-scope fence this does not wait for the in-flight prefetch of the next tile (vmcnt).
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// candidate buffers may instead live in HBM (2 workgroups per CU variant): then other lanes' stores
+// must have left the wave before they are read back
+__device__ __forceinline__ void cand_fence(bool hbm) {
+    if (hbm) {
+        wg_fence();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        lds_fence();
+    }
+}
 
 // radix-select compaction of ONE query's LDS buffer (<= 64 entries, one per lane); see topk_buffer.h
 __device__ __forceinline__ void compact_lds(uint32_t *__restrict__ ck, uint32_t *__restrict__ ci, uint32_t n,
-                                            uint32_t kp, int lane, uint32_t *tau_slot, uint32_t *cnt_slot) {
+                                            uint32_t kp, int lane, uint32_t *tau_slot, uint32_t *cnt_slot,
+                                            bool hbm = false) {
     if (lane == 0) PN_COUNT(1, 1);
     const bool valid = (uint32_t)lane < n;
     const uint32_t key = valid ? ck[lane] : 0xFFFFFFFFu;
@@ -92,7 +103,7 @@ __device__ __forceinline__ void compact_lds(uint32_t *__restrict__ ck, uint32_t 
     }
     const bool keep = less || (eq && ix <= row_cut);
     const unsigned long long mask = __ballot(keep);
-    lds_fence();  // all lanes have read their entry
+    cand_fence(hbm);  // all lanes have read their entry
     if (keep) {
         const uint32_t o = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         ck[o] = key;
@@ -102,7 +113,7 @@ __device__ __forceinline__ void compact_lds(uint32_t *__restrict__ ck, uint32_t 
         *tau_slot = T;
         *cnt_slot = (uint32_t)__popcll(mask);
     }
-    lds_fence();
+    cand_fence(hbm);
 }
 
 // append the survivors of one 32-row block (16 registers per lane) to the lane's query buffer
@@ -222,7 +233,7 @@ __device__ __forceinline__ void v2_dma_tile(const float *__restrict__ P, const f
 __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, float &tau, uint32_t row0, int h,
                                         int wave, int lane, uint32_t kp, uint32_t *cand_k, uint32_t *cand_i,
                                         uint32_t *taus_w, uint32_t *cnts_w, uint32_t *ckq, uint32_t *ciq,
-                                        uint32_t *cnt_q, uint32_t *tau_q) {
+                                        uint32_t *cnt_q, uint32_t *tau_q, bool hbm) {
     if (lane == 0) PN_COUNT(0, 1);
     if (__any(sc.npass > 1)) {
         append_block(acc, tau, row0, h, ckq, ciq, cnt_q);
@@ -232,7 +243,7 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
         ckq[o] = f2s(sc.m);
         ciq[o] = row0 + (sc.am & 3) + 8 * (sc.am >> 2) + 4 * h;  // C/D map of the 32x32 MFMA
     }
-    lds_fence();
+    cand_fence(hbm);
     const uint32_t c = *cnt_q;
     unsigned long long need = __ballot(h == 0 && c > kV2Cap - 32);
     if (need) {
@@ -241,7 +252,7 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
             need &= need - 1;
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
             compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap, cj, kp, lane,
-                        &taus_w[j], &cnts_w[j]);
+                        &taus_w[j], &cnts_w[j], hbm);
         } while (need);
         tau = s2f(*tau_q);
     }
@@ -252,7 +263,7 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
 //   chain(block 0 of rt) -> acc0   while filtering acc1 = block 1 of tile rt-1
 //   chain(block 1 of rt) -> acc1   while filtering acc0
 // then tile rt+1 is written to the other LDS buffer and the workgroup meets at ONE barrier.
-template <int NKG>
+template <int NKG, bool GC>
 __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float *__restrict__ pnorm, float *tiles,
                                         float *pnl, uint32_t *cand_k, uint32_t *cand_i, uint32_t *taus_w,
                                         uint32_t *cnts_w, uint32_t *ckq, uint32_t *ciq, uint32_t *cnt_q,
@@ -294,7 +305,7 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
     if (__any(s1.npass != 0)) {
         PN_T0();
         v2_slow(acc1, s1, tau, (rt - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq,
-                cnt_q, tau_q);
+                cnt_q, tau_q, GC);
         PN_T1(3);
     }
 #endif
@@ -304,7 +315,7 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
 #else
     if (__any(s0.npass != 0)) {
         PN_T0();
-        v2_slow(acc0, s0, tau, rt * kV2P, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q);
+        v2_slow(acc0, s0, tau, rt * kV2P, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, GC);
         PN_T1(3);
     }
 #endif
@@ -334,19 +345,25 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
 #endif
 }
 
-template <int NKG>
-__global__ __launch_bounds__(256, 1) void mfma_filter_v2_kernel(
+// GC = false: candidate buffers in LDS, one workgroup per CU.  GC = true: candidate buffers in HBM
+// (one 64 KB slab per workgroup in `gcand`), LDS holds only the tiles -> two workgroups per CU, so
+// each SIMD has a second wave to run while the first sits in its rare path, at a barrier or at the
+// head of a chain.
+template <int NKG, bool GC>
+__global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_v2_kernel(
     const float *__restrict__ P, const float *__restrict__ pnorm, uint32_t n_tiles, const float *__restrict__ Q,
     const float *__restrict__ qnorm, uint32_t q_tiles, uint32_t kp, uint32_t *__restrict__ ckey,
-    uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad) {
+    uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad,
+    uint32_t *__restrict__ gcand) {
     constexpr int LD = V2Ctx<NKG>::LD, STR = V2Ctx<NKG>::STR, CHUNKS = V2Ctx<NKG>::CHUNKS, NLD = V2Ctx<NKG>::NLD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *tiles = reinterpret_cast<float *>(smem_raw);                   // [2][64][STR]
     float *pnl = tiles + 2 * kV2P * STR;                                  // [2][64]
-    uint32_t *cand_k = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);      // [128][64]
-    uint32_t *cand_i = cand_k + kV2Q * kV2Cap;                            // [128][64]
-    uint32_t *taus = cand_i + kV2Q * kV2Cap;                              // [128]
-    uint32_t *cnts = taus + kV2Q;                                         // [128]
+    uint32_t *lds_tail = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);
+    uint32_t *cand_k = GC ? gcand + (size_t)blockIdx.x * (2 * kV2Q * kV2Cap) : lds_tail;  // [128][64]
+    uint32_t *cand_i = cand_k + kV2Q * kV2Cap;                                             // [128][64]
+    uint32_t *taus = GC ? lds_tail : cand_i + kV2Q * kV2Cap;                               // [128]
+    uint32_t *cnts = taus + kV2Q;                                                          // [128]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jq = lane & 31, h = lane >> 5;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_v2_kernel(
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = __uint_as_float(0x7F800000u); }
         int cur = 0;
         for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1)
-            v2_step<NKG>(P, pnorm, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, b, foff, bn, tau,
+            v2_step<NKG, GC>(P, pnorm, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, b, foff, bn, tau,
                          st, stn, rt, rt1, cur, acc0, acc1, kp, tid, wave, lane, jq, h, lane_off);
         {  // drain: second block of the last tile
             BlockScan sc{acc1[0], 0, acc1[0] < tau ? 1u : 0u};
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_v2_kernel(
 #ifndef PN_DIAG_NO_SLOWPATH
             if (__any(sc.npass != 0))
                 v2_slow(acc1, sc, tau, (rt1 - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq,
-                        ciq, cnt_q, tau_q);
+                        ciq, cnt_q, tau_q, GC);
 #else
             asm volatile("" ::"v"(sc.m));
 #endif
@@ -454,9 +471,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_v2_kernel(
                 need &= need - 1;
                 const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
                 compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap, cj, kp, lane,
-                            &taus_w[j], &cnts_w[j]);
+                            &taus_w[j], &cnts_w[j], GC);
             }
-            lds_fence();
+            cand_fence(GC);
             const size_t gq = (size_t)seg * nq_pad + q0;  // first query of this wave in [seg][query]
             for (int j = 0; j < 32; ++j) {
                 const uint32_t cj = cnts_w[j];
@@ -891,12 +908,12 @@ int mfma_v2_max_segments(size_t q_tiles, int n_wg) {
     return (int)((n_wg + q_tiles - 1) / q_tiles) + 1;
 }
 
-template <int NKG>
+template <int NKG, bool GC>
 static hipError_t launch_v2(const float *P, const float *pnorm, uint32_t n_tiles, const float *Q, const float *qnorm,
-                            uint32_t q_tiles, uint32_t kp, const CandBuf &cb, int n_wg, hipStream_t s) {
+                            uint32_t q_tiles, uint32_t kp, const CandBuf &cb, int n_wg, uint32_t *gcand, hipStream_t s) {
     const size_t sh = (size_t)(2 * kV2P * V2Ctx<NKG>::STR + 2 * kV2P) * sizeof(float) +
-                      (size_t)(2 * kV2Q * kV2Cap + 2 * kV2Q) * sizeof(uint32_t);
-    auto kern = mfma_filter_v2_kernel<NKG>;
+                      (size_t)((GC ? 0 : 2 * kV2Q * kV2Cap) + 2 * kV2Q) * sizeof(uint32_t);
+    auto kern = mfma_filter_v2_kernel<NKG, GC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -905,14 +922,17 @@ static hipError_t launch_v2(const float *P, const float *pnorm, uint32_t n_tiles
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles, kp,
-                       static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad);
+                       static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad,
+                       gcand);
     return hipGetLastError();
 }
+
+size_t mfma_v2_gcand_bytes(int n_wg) { return (size_t)n_wg * 2 * kV2Q * kV2Cap * sizeof(uint32_t); }
 
 // cb: keys/idx [nseg][nq_pad][32], cnt/tau [nseg][nq_pad] PRE-INITIALISED to 0 / sortable(+inf)
 hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
                                      const float *qnorm, size_t ldq, int kp, const CandBuf &cb, int n_wg,
-                                     hipStream_t s) {
+                                     uint32_t *gcand, hipStream_t s) {
     if (ldq != ldp || cb.nq_pad % kV2Q || kp < 1 || kp > (int)kV2Keep || cb.cap != (int)kV2Keep)
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kV2P - 1) / kV2P);
@@ -935,12 +955,24 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
         return hipGetLastError();
     }
     switch (ldp) {
-        case 8: return launch_v2<1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
-        case 16: return launch_v2<2>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
-        case 32: return launch_v2<4>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
-        case 64: return launch_v2<8>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
-        case 96: return launch_v2<12>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
-        case 128: return launch_v2<16>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, s);
+        case 8:
+            return gcand ? launch_v2<1, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<1, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 16:
+            return gcand ? launch_v2<2, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<2, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 32:
+            return gcand ? launch_v2<4, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<4, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 64:
+            return gcand ? launch_v2<8, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<8, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 96:
+            return gcand ? launch_v2<12, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<12, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 128:
+            return gcand ? launch_v2<16, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
+                         : launch_v2<16, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
         default: return hipErrorInvalidValue;
     }
 }

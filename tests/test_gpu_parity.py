@@ -87,6 +87,15 @@ def test_reference_golden_vectors_on_gpu(pn, kats):
     assert n_ops >= 20
 
 
+def test_vantage_point_tree_facade(pn, kats):
+    """euclidian (src/vantage_point_tree.rs:220-233): nearest of [0.95, 1.96] is row 0."""
+    v = [x for x in kats["vectors"] if x["id"] == "G13"][0]
+    vp = pn.VantagePointTree.euclidean(np.array(v["points"]))
+    assert vp.query_nearest(np.array(v["ops"][0]["point"]))[0] == v["ops"][0]["expect_idx"]
+    with pytest.raises(pn.ArrayError.Empty):
+        pn.VantagePointTree.euclidean(np.zeros((0, 2)))
+
+
 def test_reference_property_test_on_gpu(pn, oracle_mod, kats):
     """ball_tree_query (src/ball_tree.rs:742-765): 40x3 f64, 10 queries, k=5 == naive scan."""
     pt = kats["property_test"]
@@ -302,10 +311,11 @@ def test_mfma_filter_slot_count_does_not_change_results(pn, oracle_mod, slots):
     _check_knn(pn, oracle_mod, pts, qs, 10, "mfma", {_lib.PN_OPT_FILTER_SLOTS: slots, _lib.PN_OPT_SEGMENTS: 3})
 
 
-@pytest.mark.parametrize("structure", [1, 2])
+@pytest.mark.parametrize("structure", [1, 2, 3])
 @pytest.mark.parametrize("n,dim,nq,k", [(40000, 128, 300, 10), (9000, 96, 130, 20), (2000, 16, 700, 3), (300, 8, 5, 1)])
 def test_mfma_both_kernel_structures(pn, oracle_mod, structure, n, dim, nq, k):
-    """structure 1 = (query tile x segment) grid, structure 2 = persistent balanced partition (k' <= 32)."""
+    """structure 1 = (query tile x segment) grid; 2 / 3 = persistent balanced partition with LDS / HBM
+    candidate buffers (k' <= 30)."""
     from petal_neighbors_amd import _lib
     pts = uniform((n, dim), 0xC0FFEE + n, np.float32)
     qs = np.concatenate([pts[: nq // 4], uniform((nq - nq // 4, dim), 0xF00D + n, np.float32)])
