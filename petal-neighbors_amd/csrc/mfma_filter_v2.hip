@@ -188,6 +188,12 @@ __device__ __forceinline__ BlockScan v2_chain(const float *trow, const int (&fof
         w = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * kg + 3], w, 0, 0, 0);
         a = nx;
         if (kg == 0) {  // scan of the other block: issued behind the first MFMAs
+#ifdef PN_LIGHT_SCAN
+            // minimum only (8 v_min3); the rare path recomputes which register and how many
+#pragma unroll
+            for (int i = 1; i < 16; ++i) sc.m = fminf(sc.m, r[i]);
+            sc.npass = sc.m < tau ? 1u : 0u;
+#else
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
                 const bool lt = r[i] < sc.m;
@@ -195,6 +201,7 @@ __device__ __forceinline__ BlockScan v2_chain(const float *trow, const int (&fof
                 sc.am = lt ? i : sc.am;
                 sc.npass += r[i] < tau ? 1u : 0u;
             }
+#endif
         }
     }
     // norm step last: its LDS operand has had the whole chain to arrive
@@ -235,7 +242,11 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
                                         uint32_t *taus_w, uint32_t *cnts_w, uint32_t *ckq, uint32_t *ciq,
                                         uint32_t *cnt_q, uint32_t *tau_q, bool hbm) {
     if (lane == 0) PN_COUNT(0, 1);
+#ifdef PN_LIGHT_SCAN
+    if (true) {
+#else
     if (__any(sc.npass > 1)) {
+#endif
         append_block(acc, tau, row0, h, ckq, ciq, cnt_q);
     } else if (sc.npass) {
         PN_COUNT(2, 1);
