@@ -189,7 +189,7 @@ def main():
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
         engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
         kernel_name = (("mfma_filter_wide_kernel" if dim > 128 else
-                        "mfma_filter_v2_kernel" if (k + 2 <= 30 and args.structure != 1 and not args.slots > 30)
+                        "mfma_filter_v2_kernel" if (args.structure != 1 and k + 2 + k // 16 <= 224 and args.slots <= 224)
                         else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel")
         # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same
         # command (counters cannot be read in-process); the committed summary is used when it describes

@@ -494,8 +494,8 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
 static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
     if (ix->filter_slots > 0) return (size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots;
     const size_t q_tiles = nq_pad / 128;
-    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu && kout + 2 <= 30;  // (>= 3 segments even with one workgroup per CU)
-    if (many_segments) return kout + 2;
+    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu;  // >= 3 segments per query tile
+    if (many_segments && kout + 2 + kout / 16 <= 224) return kout + 2 + kout / 16;
     return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
 
@@ -556,9 +556,12 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
                     float *d_dist, hipStream_t s) {
     // candidate slots kept per (segment, query)
     const size_t kp = mfma_slots(ix, kout, nq_pad);
-    const bool v2 = kp <= 30 && (ix->mfma_structure != 1 || ix->ld > 128);  // 64 LDS slots, compaction above 32 in use
+    // persistent-partition kernels: k' <= 30 with LDS candidate buffers (structure 2, wide rows), k' <= 224 with
+    // HBM candidate buffers and two workgroups per CU (structure 3, the default for D <= 128)
+    const bool hbm_ok = ix->ld <= 128 && (ix->mfma_structure == 0 || ix->mfma_structure == 3);
+    const bool v2 = ix->mfma_structure != 1 && (kp <= 30 || (hbm_ok && kp <= 224));
     if (!v2 && ix->ld > 128) return fail(PN_ERR_UNSUPPORTED, "wide rows need k' <= 30 on the MFMA path");
-    int cap = v2 ? 32 : pick_cap(kp);
+    int cap = v2 ? (int)round_up(kp, 32) : pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
     // scaled query norms (same kernel as the corpus norms)
     PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
@@ -571,7 +574,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
                                 d_nflag + 1, s));
     MfmaPlan plan{};
     // structure 3: persistent partition with HBM candidate buffers and two workgroups per CU
-    const bool two_per_cu = v2 && (ix->mfma_structure == 3 || ix->mfma_structure == 0) && ix->ld <= 128;
+    const bool two_per_cu = v2 && hbm_ok;
     int n_wg = two_per_cu ? 2 * ix->n_cu : ix->n_cu;
     if (v2) {
         // at most ~32 workgroups per query tile and at least ~32 row tiles per workgroup
@@ -605,7 +608,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
     uint32_t *gcand = nullptr;
     if (two_per_cu) {
-        PNCHK(ix->w_sel.ensure(mfma_v2_gcand_bytes(n_wg)));
+        PNCHK(ix->w_sel.ensure(mfma_v2_gcand_bytes(n_wg, (int)kp)));
         gcand = (uint32_t *)ix->w_sel.p;
     }
     if (v2)

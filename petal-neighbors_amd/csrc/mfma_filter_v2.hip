@@ -237,6 +237,7 @@ __device__ __forceinline__ void v2_dma_tile(const float *__restrict__ P, const f
 // rare path: append the survivors of one 32-row block, compact where more than 32 slots are used.
 // Steady state: a lane has at most ONE survivor, which is its minimum -- appended without looking
 // at the other 15 registers; the general 16-way descent runs only when some lane has several.
+template <int M>
 __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, float &tau, uint32_t row0, int h,
                                         int wave, int lane, uint32_t kp, uint32_t *cand_k, uint32_t *cand_i,
                                         uint32_t *taus_w, uint32_t *cnts_w, uint32_t *ckq, uint32_t *ciq,
@@ -255,15 +256,20 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
         ciq[o] = row0 + (sc.am & 3) + 8 * (sc.am >> 2) + 4 * h;  // C/D map of the 32x32 MFMA
     }
     cand_fence(hbm);
+    constexpr uint32_t CAP = 64u * M;
     const uint32_t c = *cnt_q;
-    unsigned long long need = __ballot(h == 0 && c > kV2Cap - 32);
+    unsigned long long need = __ballot(h == 0 && c > CAP - 32);
     if (need) {
         do {
             const int j = __builtin_ctzll(need);
             need &= need - 1;
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-            compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap, cj, kp, lane,
-                        &taus_w[j], &cnts_w[j], hbm);
+            if constexpr (M == 1)
+                compact_lds(cand_k + (wave * 32 + j) * CAP, cand_i + (wave * 32 + j) * CAP, cj, kp, lane, &taus_w[j],
+                            &cnts_w[j], hbm);
+            else  // larger buffers live in HBM only: the generic radix-select compaction (topk_buffer.h)
+                compact_query<uint32_t, M>(cand_k, cand_i, (size_t)(wave * 32 + j) * CAP, cj, kp, lane, &taus_w[j],
+                                           &cnts_w[j], 0xFFFFFFFFu);
         } while (need);
         tau = s2f(*tau_q);
     }
@@ -274,7 +280,7 @@ __device__ __forceinline__ void v2_slow(const f32x16 &acc, const BlockScan &sc, 
 //   chain(block 0 of rt) -> acc0   while filtering acc1 = block 1 of tile rt-1
 //   chain(block 1 of rt) -> acc1   while filtering acc0
 // then tile rt+1 is written to the other LDS buffer and the workgroup meets at ONE barrier.
-template <int NKG, bool GC>
+template <int NKG, bool GC, int M>
 __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float *__restrict__ pnorm, float *tiles,
                                         float *pnl, uint32_t *cand_k, uint32_t *cand_i, uint32_t *taus_w,
                                         uint32_t *cnts_w, uint32_t *ckq, uint32_t *ciq, uint32_t *cnt_q,
@@ -315,7 +321,7 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
 #else
     if (__any(s1.npass != 0)) {
         PN_T0();
-        v2_slow(acc1, s1, tau, (rt - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq,
+        v2_slow<M>(acc1, s1, tau, (rt - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq,
                 cnt_q, tau_q, GC);
         PN_T1(3);
     }
@@ -326,7 +332,7 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
 #else
     if (__any(s0.npass != 0)) {
         PN_T0();
-        v2_slow(acc0, s0, tau, rt * kV2P, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, GC);
+        v2_slow<M>(acc0, s0, tau, rt * kV2P, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, GC);
         PN_T1(3);
     }
 #endif
@@ -360,26 +366,28 @@ __device__ __forceinline__ void v2_step(const float *__restrict__ P, const float
 // (one 64 KB slab per workgroup in `gcand`), LDS holds only the tiles -> two workgroups per CU, so
 // each SIMD has a second wave to run while the first sits in its rare path, at a barrier or at the
 // head of a chain.
-template <int NKG, bool GC>
+template <int NKG, bool GC, int M>
 __global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_v2_kernel(
     const float *__restrict__ P, const float *__restrict__ pnorm, uint32_t n_tiles, const float *__restrict__ Q,
     const float *__restrict__ qnorm, uint32_t q_tiles, uint32_t kp, uint32_t *__restrict__ ckey,
     uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad,
-    uint32_t *__restrict__ gcand) {
+    uint32_t *__restrict__ gcand, uint32_t keep) {
+    static_assert(GC || M == 1, "LDS candidate buffers hold 64 slots per query");
+    constexpr uint32_t CAP = 64u * M;  // candidate slots per query (HBM buffers may be larger than 64)
     constexpr int LD = V2Ctx<NKG>::LD, STR = V2Ctx<NKG>::STR, CHUNKS = V2Ctx<NKG>::CHUNKS, NLD = V2Ctx<NKG>::NLD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *tiles = reinterpret_cast<float *>(smem_raw);                   // [2][64][STR]
     float *pnl = tiles + 2 * kV2P * STR;                                  // [2][64]
     uint32_t *lds_tail = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);
-    uint32_t *cand_k = GC ? gcand + (size_t)blockIdx.x * (2 * kV2Q * kV2Cap) : lds_tail;  // [128][64]
-    uint32_t *cand_i = cand_k + kV2Q * kV2Cap;                                             // [128][64]
-    uint32_t *taus = GC ? lds_tail : cand_i + kV2Q * kV2Cap;                               // [128]
+    uint32_t *cand_k = GC ? gcand + (size_t)blockIdx.x * (2 * kV2Q * CAP) : lds_tail;  // [128][CAP]
+    uint32_t *cand_i = cand_k + kV2Q * CAP;                                             // [128][CAP]
+    uint32_t *taus = GC ? lds_tail : cand_i + kV2Q * CAP;                               // [128]
     uint32_t *cnts = taus + kV2Q;                                                          // [128]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jq = lane & 31, h = lane >> 5;
     const int ql = wave * 32 + jq;  // this lane's query within the workgroup tile
-    uint32_t *ckq = cand_k + ql * kV2Cap, *ciq = cand_i + ql * kV2Cap;
+    uint32_t *ckq = cand_k + ql * CAP, *ciq = cand_i + ql * CAP;
     uint32_t *cnt_q = cnts + ql, *tau_q = taus + ql;
     uint32_t *taus_w = taus + wave * 32, *cnts_w = cnts + wave * 32;
     const uint32_t lane_off = (uint32_t)tid * 16u;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_v2_kernel(
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = __uint_as_float(0x7F800000u); }
         int cur = 0;
         for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1)
-            v2_step<NKG, GC>(P, pnorm, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, b, foff, bn, tau,
+            v2_step<NKG, GC, M>(P, pnorm, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, b, foff, bn, tau,
                          st, stn, rt, rt1, cur, acc0, acc1, kp, tid, wave, lane, jq, h, lane_off);
         {  // drain: second block of the last tile
             BlockScan sc{acc1[0], 0, acc1[0] < tau ? 1u : 0u};
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_v2_kernel(
             }
 #ifndef PN_DIAG_NO_SLOWPATH
             if (__any(sc.npass != 0))
-                v2_slow(acc1, sc, tau, (rt1 - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq,
+                v2_slow<M>(acc1, sc, tau, (rt1 - 1) * kV2P + 32, h, wave, lane, kp, cand_k, cand_i, taus_w, cnts_w, ckq,
                         ciq, cnt_q, tau_q, GC);
 #else
             asm volatile("" ::"v"(sc.m));
@@ -481,16 +489,20 @@ __global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_v2_kernel(
                 const int j = __builtin_ctzll(need);
                 need &= need - 1;
                 const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-                compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap, cj, kp, lane,
-                            &taus_w[j], &cnts_w[j], GC);
+                if constexpr (M == 1)
+                    compact_lds(cand_k + (wave * 32 + j) * CAP, cand_i + (wave * 32 + j) * CAP, cj, kp, lane,
+                                &taus_w[j], &cnts_w[j], GC);
+                else
+                    compact_query<uint32_t, M>(cand_k, cand_i, (size_t)(wave * 32 + j) * CAP, cj, kp, lane, &taus_w[j],
+                                               &cnts_w[j], 0xFFFFFFFFu);
             }
             cand_fence(GC);
             const size_t gq = (size_t)seg * nq_pad + q0;  // first query of this wave in [seg][query]
             for (int j = 0; j < 32; ++j) {
                 const uint32_t cj = cnts_w[j];
-                if ((uint32_t)lane < cj) {
-                    ckey[(gq + j) * kV2Keep + lane] = cand_k[(wave * 32 + j) * kV2Cap + lane];
-                    cidx[(gq + j) * kV2Keep + lane] = cand_i[(wave * 32 + j) * kV2Cap + lane];
+                for (uint32_t e = lane; e < cj; e += 64) {
+                    ckey[(gq + j) * keep + e] = cand_k[(wave * 32 + j) * CAP + e];
+                    cidx[(gq + j) * keep + e] = cand_i[(wave * 32 + j) * CAP + e];
                 }
             }
             if (lane < 32) {
@@ -919,12 +931,12 @@ int mfma_v2_max_segments(size_t q_tiles, int n_wg) {
     return (int)((n_wg + q_tiles - 1) / q_tiles) + 1;
 }
 
-template <int NKG, bool GC>
+template <int NKG, bool GC, int M>
 static hipError_t launch_v2(const float *P, const float *pnorm, uint32_t n_tiles, const float *Q, const float *qnorm,
                             uint32_t q_tiles, uint32_t kp, const CandBuf &cb, int n_wg, uint32_t *gcand, hipStream_t s) {
     const size_t sh = (size_t)(2 * kV2P * V2Ctx<NKG>::STR + 2 * kV2P) * sizeof(float) +
-                      (size_t)((GC ? 0 : 2 * kV2Q * kV2Cap) + 2 * kV2Q) * sizeof(uint32_t);
-    auto kern = mfma_filter_v2_kernel<NKG, GC>;
+                      (size_t)((GC ? 0 : 2 * kV2Q * 64) + 2 * kV2Q) * sizeof(uint32_t);
+    auto kern = mfma_filter_v2_kernel<NKG, GC, M>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -934,17 +946,31 @@ static hipError_t launch_v2(const float *P, const float *pnorm, uint32_t n_tiles
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles, kp,
                        static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad,
-                       gcand);
+                       gcand, (uint32_t)cb.cap);
     return hipGetLastError();
 }
 
-size_t mfma_v2_gcand_bytes(int n_wg) { return (size_t)n_wg * 2 * kV2Q * kV2Cap * sizeof(uint32_t); }
+template <int NKG>
+static hipError_t launch_v2_pick(const float *P, const float *pnorm, uint32_t n_tiles, const float *Q,
+                                 const float *qnorm, uint32_t q_tiles, uint32_t kp, const CandBuf &cb, int n_wg,
+                                 uint32_t *gcand, hipStream_t s) {
+    if (!gcand) return launch_v2<NKG, false, 1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, kp, cb, n_wg, nullptr, s);
+    if (kp <= 30) return launch_v2<NKG, true, 1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, kp, cb, n_wg, gcand, s);
+    if (kp <= 94) return launch_v2<NKG, true, 2>(P, pnorm, n_tiles, Q, qnorm, q_tiles, kp, cb, n_wg, gcand, s);
+    return launch_v2<NKG, true, 4>(P, pnorm, n_tiles, Q, qnorm, q_tiles, kp, cb, n_wg, gcand, s);
+}
+
+// slots per query in the HBM candidate buffers for a given k'
+int mfma_v2_cap_for(int kp) { return kp <= 30 ? 64 : kp <= 94 ? 128 : 256; }
+size_t mfma_v2_gcand_bytes(int n_wg, int kp) {
+    return (size_t)n_wg * 2 * kV2Q * (size_t)mfma_v2_cap_for(kp) * sizeof(uint32_t);
+}
 
 // cb: keys/idx [nseg][nq_pad][32], cnt/tau [nseg][nq_pad] PRE-INITIALISED to 0 / sortable(+inf)
 hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
                                      const float *qnorm, size_t ldq, int kp, const CandBuf &cb, int n_wg,
                                      uint32_t *gcand, hipStream_t s) {
-    if (ldq != ldp || cb.nq_pad % kV2Q || kp < 1 || kp > (int)kV2Keep || cb.cap != (int)kV2Keep)
+    if (ldq != ldp || cb.nq_pad % kV2Q || kp < 1 || kp > cb.cap || kp > (gcand && ldp <= 128 ? 224 : 30))
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kV2P - 1) / kV2P);
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kV2Q);
@@ -966,24 +992,12 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
         return hipGetLastError();
     }
     switch (ldp) {
-        case 8:
-            return gcand ? launch_v2<1, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<1, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
-        case 16:
-            return gcand ? launch_v2<2, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<2, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
-        case 32:
-            return gcand ? launch_v2<4, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<4, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
-        case 64:
-            return gcand ? launch_v2<8, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<8, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
-        case 96:
-            return gcand ? launch_v2<12, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<12, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
-        case 128:
-            return gcand ? launch_v2<16, true>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s)
-                         : launch_v2<16, false>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, nullptr, s);
+        case 8: return launch_v2_pick<1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
+        case 16: return launch_v2_pick<2>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
+        case 32: return launch_v2_pick<4>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
+        case 64: return launch_v2_pick<8>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
+        case 96: return launch_v2_pick<12>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
+        case 128: return launch_v2_pick<16>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -118,7 +118,8 @@ const char *mfma_kernel_name();
 // second structure (mfma_filter_v2.hip): persistent balanced partition, k' <= 32, 32 slots per (segment, query)
 int mfma_v2_max_segments(size_t q_tiles, int n_wg);
 // gcand != nullptr: candidate buffers in HBM (mfma_v2_gcand_bytes(n_wg) bytes), 2 workgroups per CU
-size_t mfma_v2_gcand_bytes(int n_wg);
+size_t mfma_v2_gcand_bytes(int n_wg, int kp);
+int mfma_v2_cap_for(int kp);
 hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t n, size_t ldp, const float *Q,
                                      const float *qnorm, size_t ldq, int kp, const CandBuf &cb, int n_wg,
                                      uint32_t *gcand, hipStream_t s);
