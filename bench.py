@@ -43,6 +43,7 @@ CONFIGS = {
     "c3s": (1_000_000, 128, 10_000, 100),
     "c4s": (1_000_000, 768, 10_000, 10),
     "c5s": (1_000_000, 96, 10_000, 10),
+    "c5shard": (12_500_000, 96, 1_000_000, 10),  # one of the 8 row shards of configs[4]
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
@@ -185,7 +186,8 @@ def main():
         # dominant kernel: one launch covers all nq queries against this rank's shard
         launches = max(int(st["hot_launches"]), 1)
         hot_ms = st["hot_ms"] / launches
-        flops_per_launch = 2.0 * n_local * dim * nq  # 2*N*D per query
+        # 2*N*D flop per query; a step of more than 262 144 queries is served in several launches
+        flops_per_launch = 2.0 * n_local * dim * nq * args.steps / launches
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
         engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
         kernel_name = (("mfma_filter_wide_kernel" if dim > 128 else

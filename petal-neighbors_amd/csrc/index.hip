@@ -522,7 +522,7 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
     const size_t chunk = 1u << 18;
     for (size_t qs = 0; qs < nq; qs += chunk) {
         const size_t nqc = (nq - qs < chunk) ? nq - qs : chunk;
-        const size_t nq_pad = round_up(nqc, (size_t)kRowPad);
+        const size_t nq_pad = round_up(nqc, (size_t)128);  // query tiles are 64 (exact) or 128 (MFMA) rows
         PNCHK(ix->w_q.ensure(nq_pad * ix->ld * sizeof(T)));
         T *Qp = (T *)ix->w_q.p;
         HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
@@ -558,8 +558,8 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     const size_t kp = mfma_slots(ix, kout, nq_pad);
     // persistent-partition kernels: k' <= 30 with LDS candidate buffers (structure 2, wide rows), k' <= 224 with
     // HBM candidate buffers and two workgroups per CU (structure 3, the default for D <= 128)
-    const bool hbm_ok = ix->ld <= 128 && (ix->mfma_structure == 0 || ix->mfma_structure == 3);
-    const bool v2 = ix->mfma_structure != 1 && (kp <= 30 || (hbm_ok && kp <= 224));
+    const bool hbm_ok = (ix->mfma_structure == 0 || ix->mfma_structure == 3);
+    const bool v2 = ix->mfma_structure != 1 && (kp <= 30 || (hbm_ok && ix->ld <= 128 && kp <= 224));
     if (!v2 && ix->ld > 128) return fail(PN_ERR_UNSUPPORTED, "wide rows need k' <= 30 on the MFMA path");
     int cap = v2 ? (int)round_up(kp, 32) : pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
@@ -634,7 +634,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (h.nflag) {
         // re-run the unproven queries on the exact engine
         const size_t nf = h.nflag;
-        const size_t nf_pad = round_up(nf, (size_t)kRowPad);
+        const size_t nf_pad = round_up(nf, (size_t)128);
         PNCHK(ix->w_sel.ensure(nq * sizeof(uint32_t)));
         PNCHK(ix->w_fq.ensure(nf_pad * ix->ld * sizeof(float)));
         PNCHK(ix->w_fidx.ensure(nf * kout * sizeof(uint64_t)));
@@ -848,7 +848,7 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
     std::lock_guard<std::mutex> lk(ix->mu);
     hipStream_t s = ix->stream;
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
-    const size_t nq_pad = round_up(nq, (size_t)kRowPad);
+    const size_t nq_pad = round_up(nq, (size_t)128);
     T *d_q = nullptr;
     uint32_t *d_counts = nullptr;
     uint64_t *d_offs = nullptr, *d_fill = nullptr;

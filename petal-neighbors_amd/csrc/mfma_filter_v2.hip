@@ -566,11 +566,12 @@ __device__ __forceinline__ void wide_dma_slab(const float *__restrict__ P, size_
 }
 
 // one slab: DMA + B prefetch for the next slab, two 64-MFMA chains, (last chunk) norm + filter, barrier
+template <bool GC>
 __device__ __forceinline__ void wide_step(const float *__restrict__ P, const float *__restrict__ pnorm, size_t ldp,
                                           const float *__restrict__ qbase, float *tiles, float *pnl, uint32_t *cand_k,
                                           uint32_t *cand_i, uint32_t *taus_w, uint32_t *cnts_w, uint32_t *ckq,
                                           uint32_t *ciq, uint32_t *cnt_q, uint32_t *tau_q, const int (&foff)[16],
-                                          float bn, float &tau, const float (&bcur)[64], float (&bnext)[64],
+                                          float bn, float &tau, float (&bcur)[64], float (&bnext)[64],
                                           uint32_t s, uint32_t total, uint32_t rt0, int nc, f32x16 &acc0, f32x16 &acc1,
                                           uint32_t kp, int wave, int lane, int jq, int h) {
     const uint32_t rt = rt0 + s / nc;
@@ -583,8 +584,11 @@ __device__ __forceinline__ void wide_step(const float *__restrict__ P, const flo
         if (cn == 0 && __builtin_amdgcn_readfirstlane(wave) == 0)
             __builtin_amdgcn_global_load_lds((glb_void *)(pnorm + (size_t)rtn * kV2P + lane),
                                              (lds_void *)(pnl + (rtn & 1) * kV2P), 4, 0, 0);
-        wide_load_b(qbase + (size_t)cn * 128, bnext);
+        if (!GC) wide_load_b(qbase + (size_t)cn * 128, bnext);
     }
+    // two workgroups per CU: one register set, loaded for THIS slab; the other workgroup's wave on the
+    // SIMD covers the L2 latency
+    if (GC) wide_load_b(qbase + (size_t)c * 128, bcur);
     if (c == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -602,7 +606,7 @@ __device__ __forceinline__ void wide_step(const float *__restrict__ P, const flo
         for (int r = 1; r < 16; ++r) { m0 = fminf(m0, acc0[r]); m1 = fminf(m1, acc1[r]); }
         if (__any(m0 < tau)) {
             append_block(acc0, tau, rt * kV2P, h, ckq, ciq, cnt_q);
-            lds_fence();
+            cand_fence(GC);
             const uint32_t cq = *cnt_q;
             unsigned long long need = __ballot(h == 0 && cq > kV2Cap - 32);
             if (need) {
@@ -610,14 +614,14 @@ __device__ __forceinline__ void wide_step(const float *__restrict__ P, const flo
                     const int j = __builtin_ctzll(need);
                     need &= need - 1;
                     compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
-                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j]);
+                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j], GC);
                 } while (need);
                 tau = s2f(*tau_q);
             }
         }
         if (__any(m1 < tau)) {
             append_block(acc1, tau, rt * kV2P + 32, h, ckq, ciq, cnt_q);
-            lds_fence();
+            cand_fence(GC);
             const uint32_t cq = *cnt_q;
             unsigned long long need = __ballot(h == 0 && cq > kV2Cap - 32);
             if (need) {
@@ -625,7 +629,7 @@ __device__ __forceinline__ void wide_step(const float *__restrict__ P, const flo
                     const int j = __builtin_ctzll(need);
                     need &= need - 1;
                     compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
-                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j]);
+                                (uint32_t)__builtin_amdgcn_readlane((int)cq, j), kp, lane, &taus_w[j], &cnts_w[j], GC);
                 } while (need);
                 tau = s2f(*tau_q);
             }
@@ -634,16 +638,19 @@ __device__ __forceinline__ void wide_step(const float *__restrict__ P, const flo
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 1) void mfma_filter_wide_kernel(
+template <bool GC>
+__global__ __launch_bounds__(256, GC ? 2 : 1) void mfma_filter_wide_kernel(
     const float *__restrict__ P, const float *__restrict__ pnorm, uint32_t n_tiles, const float *__restrict__ Q,
     const float *__restrict__ qnorm, uint32_t q_tiles, uint32_t kp, int nc, size_t ldp, uint32_t *__restrict__ ckey,
-    uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad) {
+    uint32_t *__restrict__ cidx, uint32_t *__restrict__ ccnt, uint32_t *__restrict__ ctau, size_t nq_pad,
+    uint32_t *__restrict__ gcand) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *tiles = reinterpret_cast<float *>(smem_raw);                   // [2][64][128]
     float *pnl = tiles + 2 * kV2P * 128;                                  // [2][64]
-    uint32_t *cand_k = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);      // [128][64]
+    uint32_t *lds_tail = reinterpret_cast<uint32_t *>(pnl + 2 * kV2P);
+    uint32_t *cand_k = GC ? gcand + (size_t)blockIdx.x * (2 * kV2Q * kV2Cap) : lds_tail;  // [128][64]
     uint32_t *cand_i = cand_k + kV2Q * kV2Cap;
-    uint32_t *taus = cand_i + kV2Q * kV2Cap;
+    uint32_t *taus = GC ? lds_tail : cand_i + kV2Q * kV2Cap;
     uint32_t *cnts = taus + kV2Q;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jq = lane & 31, h = lane >> 5;
@@ -683,18 +690,25 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_wide_kernel(
         if (__builtin_amdgcn_readfirstlane(wave) == 0)
             __builtin_amdgcn_global_load_lds((glb_void *)(pnorm + (size_t)rt0 * kV2P + lane),
                                              (lds_void *)(pnl + (rt0 & 1) * kV2P), 4, 0, 0);
-        wide_load_b(qbase, bA);
+        if (!GC) wide_load_b(qbase, bA);
         __syncthreads();
 
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-        for (uint32_t s = 0; s < total; s += 2) {
-            wide_step(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, foff, bn,
-                      tau, bA, bB, s, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
-            if (s + 1 < total)
-                wide_step(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q, foff,
-                          bn, tau, bB, bA, s + 1, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
+        if constexpr (GC) {
+            for (uint32_t s = 0; s < total; ++s)
+                wide_step<true>(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q,
+                                foff, bn, tau, bA, bA, s, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
+        } else {
+            for (uint32_t s = 0; s < total; s += 2) {
+                wide_step<false>(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q, tau_q,
+                                 foff, bn, tau, bA, bB, s, total, rt0, nc, acc0, acc1, kp, wave, lane, jq, h);
+                if (s + 1 < total)
+                    wide_step<false>(P, pnorm, ldp, qbase, tiles, pnl, cand_k, cand_i, taus_w, cnts_w, ckq, ciq, cnt_q,
+                                     tau_q, foff, bn, tau, bB, bA, s + 1, total, rt0, nc, acc0, acc1, kp, wave, lane, jq,
+                                     h);
+            }
         }
 
         {  // flush this run
@@ -704,9 +718,9 @@ __global__ __launch_bounds__(256, 1) void mfma_filter_wide_kernel(
                 const int j = __builtin_ctzll(need);
                 need &= need - 1;
                 compact_lds(cand_k + (wave * 32 + j) * kV2Cap, cand_i + (wave * 32 + j) * kV2Cap,
-                            (uint32_t)__builtin_amdgcn_readlane((int)c, j), kp, lane, &taus_w[j], &cnts_w[j]);
+                            (uint32_t)__builtin_amdgcn_readlane((int)c, j), kp, lane, &taus_w[j], &cnts_w[j], GC);
             }
-            lds_fence();
+            cand_fence(GC);
             const size_t gq = (size_t)seg * nq_pad + q0;
             for (int j = 0; j < 32; ++j) {
                 const uint32_t cj = cnts_w[j];
@@ -976,20 +990,19 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kV2Q);
     if (cb.nseg < mfma_v2_max_segments(q_tiles, n_wg)) return hipErrorInvalidValue;
     if (ldp > 128) {
-        if (ldp % 128) return hipErrorInvalidValue;
+        if (ldp % 128 || kp > 30) return hipErrorInvalidValue;
         const size_t sh = (size_t)(2 * kV2P * 128 + 2 * kV2P) * sizeof(float) +
-                          (size_t)(2 * kV2Q * kV2Cap + 2 * kV2Q) * sizeof(uint32_t);
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_filter_wide_kernel),
+                          (size_t)((gcand ? 0 : 2 * kV2Q * kV2Cap) + 2 * kV2Q) * sizeof(uint32_t);
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (e != hipSuccess) return e;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(mfma_filter_wide_kernel, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm,
-                           q_tiles, (uint32_t)kp, (int)(ldp / 128), ldp, static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt,
-                           static_cast<uint32_t *>(cb.tau), cb.nq_pad);
-        return hipGetLastError();
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles,
+                               (uint32_t)kp, (int)(ldp / 128), ldp, static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt,
+                               static_cast<uint32_t *>(cb.tau), cb.nq_pad, gcand);
+            return hipGetLastError();
+        };
+        return gcand ? launch(mfma_filter_wide_kernel<true>) : launch(mfma_filter_wide_kernel<false>);
     }
     switch (ldp) {
         case 8: return launch_v2_pick<1>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
