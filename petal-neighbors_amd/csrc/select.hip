@@ -32,6 +32,65 @@ __device__ __forceinline__ uint32_t rank_of(const KeyT *skey, const IdxT *sidx, 
     return r;
 }
 
+// Shrinks n LDS entries to the (at most kout, barring duplicate entries) smallest under (key, idx), in place and
+// in their original relative order, so that rank_of runs over kout entries instead of n: a radix select on the
+// key (one ballot per 64 entries per bit), then on the index among the keys equal to the kout-th one.  One wave.
+template <typename KeyT, typename IdxT>
+__device__ __forceinline__ uint32_t prune_to_topk(KeyT *skey, IdxT *sidx, uint32_t n, uint32_t kout, int lane) {
+    if (n <= kout || n <= 128) return n;
+    KeyT T = 0;  // becomes the kout-th smallest key
+    for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
+        const KeyT cand = T | ((KeyT)1 << b);
+        uint32_t c = 0;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            c += (uint32_t)__popcll(__ballot(e < n && skey[e] < cand));
+        }
+        if (c < kout) T = cand;
+    }
+    uint32_t n_less = 0, n_eq = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const KeyT k = e < n ? skey[e] : (KeyT)0;
+        n_less += (uint32_t)__popcll(__ballot(e < n && k < T));
+        n_eq += (uint32_t)__popcll(__ballot(e < n && k == T));
+    }
+    const uint32_t need = kout - n_less;  // >= 1 entries with key == T belong to the answer
+    IdxT I = ~(IdxT)0;
+    if (n_eq > need) {
+        I = 0;  // becomes the need-th smallest index among key == T
+        for (int b = (int)sizeof(IdxT) * 8 - 1; b >= 0; --b) {
+            const IdxT cand = I | ((IdxT)1 << b);
+            uint32_t c = 0;
+            for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                c += (uint32_t)__popcll(__ballot(e < n && skey[e] == T && sidx[e] < cand));
+            }
+            if (c < need) I = cand;
+        }
+    }
+    uint32_t w = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {  // stable compaction; writes land at or below the chunk just read
+        const uint32_t e = e0 + lane;
+        KeyT k = 0;
+        IdxT ix = 0;
+        bool keep = false;
+        if (e < n) {
+            k = skey[e];
+            ix = sidx[e];
+            keep = (k < T) || (k == T && ix <= I);
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            skey[pos] = k;
+            sidx[pos] = ix;
+        }
+        w += (uint32_t)__popcll(m);
+    }
+    return w;
+}
+
 // ---------------------------------------------------------------------------
 // exact mode: block = 64 threads = one query
 // ---------------------------------------------------------------------------
@@ -63,6 +122,9 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         n += c;
     }
     __syncthreads();
+    const uint32_t n_all = n;
+    n = prune_to_topk<KeyT, uint32_t>(skey, sidx, n, (uint32_t)kout, lane);
+    __syncthreads();
     for (uint32_t e = lane; e < n; e += 64) {
         const KeyT k = skey[e];
         const uint32_t ix = sidx[e];
@@ -76,7 +138,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
             }
         }
     }
-    for (uint32_t r = n + lane; r < (uint32_t)kout; r += 64) {  // cannot happen for kout = min(k, n_points)
+    for (uint32_t r = n_all + lane; r < (uint32_t)kout; r += 64) {  // cannot happen for kout = min(k, n_points)
         idx_out[q * out_stride + out_off + r] = ~0ull;
         dist_out[q * out_stride + out_off + r] = key_to_dist(KeyOf<T>::kNaN);
     }
@@ -177,6 +239,9 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         n += c;
     }
     __syncthreads();
+    const uint32_t n_all = n;
+    n = prune_to_topk<uint32_t, uint32_t>(skey, sidx, n, (uint32_t)kout, lane);
+    __syncthreads();
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t k = skey[e];
         const uint32_t ix = sidx[e];
@@ -189,7 +254,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     }
     __syncthreads();
     if (lane == 0) {
-        bool ok = n >= (uint32_t)kout;
+        bool ok = n_all >= (uint32_t)kout;
         const uint32_t kk = kth_key;
         if (ok && kk >= 0x7F800000u) ok = false;  // k-th distance is inf/NaN: let the exact engine order it
         if (ok && min_tau < __uint_as_float(0x7F800000u)) {
@@ -203,7 +268,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         }
         flags[q] = ok ? 0u : 1u;
         if (!ok) atomicAdd(n_flagged, 1u);
-        atomicAdd(n_cand, (unsigned long long)n);
+        atomicAdd(n_cand, (unsigned long long)n_all);
     }
 }
 
@@ -301,7 +366,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
-    const uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
+    uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
     uint64_t *sidx = reinterpret_cast<uint64_t *>(smem);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
     for (uint32_t e = lane; e < n; e += 64) {
@@ -313,6 +378,10 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     }
     __syncthreads();
     uint32_t n_valid = 0;
+    for (uint32_t e = lane; e < n; e += 64) n_valid += skey[e] != KeyOf<float>::kMax;
+    for (int d = 32; d > 0; d >>= 1) n_valid += __shfl_xor(n_valid, d);
+    n = prune_to_topk<uint32_t, uint64_t>(skey, sidx, n, (uint32_t)k_out, lane);
+    __syncthreads();
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t k = skey[e];
         const uint64_t ix = sidx[e];
@@ -324,8 +393,6 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
         }
     }
     // absent tail (fewer than k_out valid entries over all parts)
-    for (uint32_t e = lane; e < n; e += 64) n_valid += skey[e] != KeyOf<float>::kMax;
-    for (int d = 32; d > 0; d >>= 1) n_valid += __shfl_xor(n_valid, d);
     for (uint32_t r = n_valid + lane; r < (uint32_t)k_out; r += 64) {
         idx_out[q * k_out + r] = ~0ull;
         dist_out[q * k_out + r] = key_to_dist(KeyOf<float>::kNaN);
