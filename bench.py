@@ -44,8 +44,11 @@ CONFIGS = {
     "c4s": (1_000_000, 768, 10_000, 10),
     "c5s": (1_000_000, 96, 10_000, 10),
     "c5shard": (12_500_000, 96, 1_000_000, 10),  # one of the 8 row shards of configs[4]
+    "c5m": (1_000_000, 96, 200_000, 10),         # many queries: one workgroup per query tile
+    "c3m": (1_000_000, 128, 200_000, 100),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # same table: dense BF16 MFMA = 16 x the f32 matrix rate ("~2.5 PF dense")
 SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
 
 
@@ -108,7 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--engine", default="auto", choices=["auto", "exact", "mfma"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "exact", "mfma", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
@@ -189,18 +192,25 @@ def main():
         # 2*N*D flop per query; a step of more than 262 144 queries is served in several launches
         flops_per_launch = 2.0 * n_local * dim * nq * args.steps / launches
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
-        engine_used = "mfma" if (tree.mfma_eligible and args.engine != "exact") else "exact"
-        kernel_name = (("mfma_filter_wide_kernel" if dim > 128 else
-                        "mfma_filter_v2_kernel" if (args.structure != 1 and k + 2 + k // 16 <= 224 and args.slots <= 224)
-                        else "mfma_filter_kernel") if engine_used == "mfma" else "exact_knn_kernel")
+        if args.engine in ("auto", "bf16") and tree.bf16_eligible and n_local >= 4096 and dim >= 8:
+            engine_used, kernel_name, peak = "bf16", "bf16_filter_kernel", PEAK_BF16_MFMA_TFLOPS
+        elif args.engine != "exact" and tree.mfma_eligible:
+            engine_used, peak = "mfma", PEAK_F32_MFMA_TFLOPS
+            kernel_name = ("mfma_filter_wide_kernel" if dim > 128 else
+                           "mfma_filter_v2_kernel" if (args.structure != 1 and k + 2 + k // 16 <= 224 and args.slots <= 224)
+                           else "mfma_filter_kernel")
+        else:
+            engine_used, kernel_name, peak = "exact", "exact_knn_kernel", PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same
-        # command (counters cannot be read in-process); the committed summary is used when it describes
+        # command (counters cannot be read in-process); a committed summary is used when it describes
         # this kernel and config on one GPU, else null.
-        traffic = None
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_v2_pmc.json")))
-            if pmc.get("kernel") == kernel_name and pmc.get("config") == args.config and world == 1:
-                traffic = pmc["hbm_bytes_per_launch"]
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+                pmc = json.load(open(f))
+                if pmc.get("kernel") == kernel_name and pmc.get("config") == args.config and world == 1:
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             pass
         line = {
@@ -212,13 +222,13 @@ def main():
             "config": {"workload": f"{args.config}: {n} points x {dim} dims f32, {nq} queries, k={k}, uniform[0,1)",
                        "n_points": n, "dim": dim, "n_queries": nq, "k": k, "engine": engine_used,
                        "sharding": f"corpus rows / {world}" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c2_v2_pmc.json)",
-                         "kernel": kernel_name,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
+                         "kernel": kernel_name, "mfma_dtype": "bf16" if engine_used == "bf16" else "f32",
                          "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
-                                                  / (PEAK_F32_MFMA_TFLOPS * world), 4)},
+                                                  / (peak * world), 4)},
             "fallback_queries": int(st["fallback_queries"]),
             "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
         }

@@ -60,9 +60,11 @@ enum {
 
 /* engine selection, PN_OPT_ENGINE */
 enum {
-    PN_ENGINE_AUTO = 0,  /* MFMA filter + exact re-rank when applicable, else exact scan */
+    PN_ENGINE_AUTO = 0,  /* bf16 filter -> f32 MFMA filter -> exact scan, each tier taking what the previous
+                            one could not prove; tiers that cannot serve the index are skipped */
     PN_ENGINE_EXACT = 1, /* exact VALU scan only (always bit-exact by construction) */
-    PN_ENGINE_MFMA = 2   /* force the MFMA filter path (f32 only); verified, falls back per query */
+    PN_ENGINE_MFMA = 2,  /* force the f32 MFMA filter path (f32 only); verified, falls back per query */
+    PN_ENGINE_BF16 = 3   /* force the bf16 MFMA filter as first tier (f32, D <= 128); verified, falls back per query */
 };
 
 enum {
@@ -83,8 +85,8 @@ typedef struct pn_info {
     uint64_t row_stride_device; /* padded row length in HBM (elements) */
     int32_t elem_bytes;         /* 4 = f32, 8 = f64 */
     int32_t device;
-    int32_t mfma_eligible; /* 1 when the MFMA filter path can serve this index */
-    int32_t reserved;
+    int32_t mfma_eligible; /* 1 when the f32 MFMA filter path can serve this index */
+    int32_t bf16_eligible; /* 1 when the bf16 MFMA filter path can serve this index */
 } pn_info;
 
 typedef struct pn_stats {
@@ -185,6 +187,14 @@ double pn_distance_to_rdistance_f64(double d);
 int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
                              size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
                              size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device, void *stream);
+
+/* ---- diagnostic: the first-tier filter's lower bounds themselves.  bounds_out[q * n_rows + i] = L'(q, p_i)
+ * for the first n_rows corpus rows (clamped to n_points), with L' + qnorm_out[q] <= |q - p_i|^2 in real
+ * arithmetic and qnorm_out[q] <= |q|^2 (petal-neighbors_amd/csrc/bf16_filter.hip states the bound).  Host
+ * pointers; q_cols must equal the index dimension.  Not part of the reference's interface: tests use it to check
+ * the inequality and to measure the matrix core's accumulation error against the allowance the proof makes. */
+int pn_bf16_bounds_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
+                       ptrdiff_t q_row_stride, size_t n_rows, float *bounds_out, double *qnorm_out);
 
 /* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
  * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpetal_mi355x.so")
 
 PN_OK, PN_ERR_EMPTY, PN_ERR_NOT_CONTIGUOUS, PN_ERR_INVALID, PN_ERR_DEVICE, PN_ERR_NOMEM, \
     PN_ERR_UNSUPPORTED, PN_ERR_EMPTY_MATRIX = range(8)
-PN_ENGINE_AUTO, PN_ENGINE_EXACT, PN_ENGINE_MFMA = 0, 1, 2
+PN_ENGINE_AUTO, PN_ENGINE_EXACT, PN_ENGINE_MFMA, PN_ENGINE_BF16 = 0, 1, 2, 3
 PN_OPT_ENGINE, PN_OPT_SEGMENTS, PN_OPT_INDEX_BASE, PN_OPT_PROFILE, PN_OPT_FILTER_SLOTS = 1, 2, 3, 4, 5
 PN_OPT_MFMA_STRUCTURE = 6
 
@@ -21,7 +21,7 @@ PN_OPT_MFMA_STRUCTURE = 6
 class PnInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("dim", C.c_uint64), ("row_stride_device", C.c_uint64),
                 ("elem_bytes", C.c_int32), ("device", C.c_int32), ("mfma_eligible", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("bf16_eligible", C.c_int32)]
 
 
 class PnStats(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "pn_distance_to_rdistance_f64": (C.c_double, [C.c_double]),
     "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
+    "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
 }
 
 _lib = None

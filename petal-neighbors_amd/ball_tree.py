@@ -19,7 +19,8 @@ from . import _lib
 from .distance import Euclidean
 from .errors import check
 
-ENGINES = {"auto": _lib.PN_ENGINE_AUTO, "exact": _lib.PN_ENGINE_EXACT, "mfma": _lib.PN_ENGINE_MFMA}
+ENGINES = {"auto": _lib.PN_ENGINE_AUTO, "exact": _lib.PN_ENGINE_EXACT, "mfma": _lib.PN_ENGINE_MFMA,
+           "bf16": _lib.PN_ENGINE_BF16}
 
 
 def _float_array(a):
@@ -44,6 +45,7 @@ class BallTree:
         check(_lib.lib().pn_index_info(self._h, C.byref(info)))
         self._n, self._dim = int(info.n_points), int(info.dim)
         self.mfma_eligible = bool(info.mfma_eligible)
+        self.bf16_eligible = bool(info.bf16_eligible)
 
     # ------------------------------------------------------------ construction
     @classmethod

@@ -30,6 +30,7 @@ UNITS = [
     ("pack.hip", []),
     ("mfma_filter.hip", []),
     ("mfma_filter_v2.hip", []),
+    ("bf16_filter.hip", []),
     ("metric.cpp", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

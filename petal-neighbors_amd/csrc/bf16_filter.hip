@@ -1,0 +1,815 @@
+// bf16_filter.hip -- first-tier filter of the k-NN path: a PROVEN lower bound of |q-p|^2 - |q|^2
+// from one bf16 MFMA contraction (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate), with the same
+// running top-k' candidate buffers, exact re-rank and per-query proof as mfma_filter_v2.hip.  The
+// results of the k-NN call do not depend on this filter's arithmetic: candidates are re-ranked with the
+// reference's exact fold (select.hip) and a query whose exclusions cannot be proven falls back to the
+// f32 engines.  Only the filter's COST depends on how tight the bound is.
+//
+// ---- the bound ------------------------------------------------------------------------------------
+// q^ = bf16(q), p^ = bf16(p) (round to nearest; |x| < 2^-60 -> 0 so no product is subnormal),
+// eq = q - q^, ep = p - p^.  Then q.p = q^.p^ + q^.ep + eq.p  <=  q^.p^ + |q^||ep| + |eq||p|, so
+//     |q-p|^2 - |q|^2  =  |p|^2 - 2 q.p  >=  |p|^2 - 2 q^.p^ - 2|q^||ep| - 2|eq||p|.
+// The right-hand side is ONE dot product of K = 16*KS bf16 columns (KS-1 data steps + one extra step):
+//     query row  [ -2 q^_k ...          | 1     1     1     -Aq  -Cq  0 ... ]
+//     corpus row [    p^_k ...          | n_hi  n_mi  n_lo   Bp   Dp  0 ... ]
+//   n_hi + n_mi + n_lo <= |p|^2 (1 - g)          (three bf16 pieces, each truncated toward zero)
+//   Aq >= |q^|,  Bp >= (2|ep| + 2 g |p^|)(1 + 2g),  Cq >= |eq|,  Dp >= 2|p|(1 + 2g)   (rounded UP to bf16)
+// bf16 x bf16 products are exact in f32; the matrix core's f32 accumulation of the K + 1 terms is assumed
+// to err by at most g * (sum of the terms' magnitudes) with g = 2^-13 -- 7x the (K+1) * 2^-23 of a
+// truncating adder tree over 145 terms; tests/test_gpu_bf16.py measures the actual error (~1e-7 * sum).
+// The magnitudes are bounded by |p|^2 + 2|q^||p^| + Aq Bp + Cq Dp, each of which is paid for above
+// (the (1-g), the 2g|p^| inside Bp, and the (1+2g) factors), so the computed value L' satisfies
+//     L'(q,p)  <=  |q-p|^2 - |q|^2     for every finite q, p with |q|^2, |p|^2 < 2^100.
+// Rows / queries outside that range raise a flag (index not eligible / query re-run exactly).
+// Padding rows carry n_hi = 1.7e38: they can enter a buffer only while its threshold is still +inf, are the
+// first to be compacted away, and select.hip ignores row numbers >= n.
+//
+// ---- the kernel -----------------------------------------------------------------------------------
+// Same persistent balanced partition and candidate-buffer protocol as mfma_filter_v2.hip; what differs
+// is sized for a matrix pipe that is 16x faster:
+//  * a workgroup is 4 waves x 64 queries (two 32-query MFMA column blocks per wave): every A fragment
+//    read from LDS feeds two MFMAs, the 2 x KS B fragments of the wave's 64 queries stay in registers;
+//  * the corpus is stored as ready-made LDS tile images (64 rows x (2 KS + 1) 16-byte chunks: the odd
+//    row pitch makes the ds_read_b128 fragment reads conflict-free), so staging is a linear LDS-DMA copy;
+//  * all per-query bookkeeping (threshold, fill count) lives in registers, appends are plain global
+//    stores into the (segment, query) buffers the select kernel reads -- no LDS atomics, no fences on
+//    the fast path, no flush copy.
+#include "pn_internal.h"
+#include "topk_buffer.h"
+
+namespace pn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_b;
+typedef const __attribute__((address_space(1))) void glb_void_b;
+
+#ifdef PN_DIAG_BF_COUNT  // diagnostic build only: event counters
+__device__ unsigned long long g_bfdbg[8];
+#define BF_COUNT(i, v) atomicAdd(&g_bfdbg[i], (unsigned long long)(v))
+__device__ __forceinline__ unsigned long long bf_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#else
+#define BF_COUNT(i, v) ((void)0)
+#endif
+
+constexpr int kBQ = 256;  // queries per workgroup (4 waves x 64)
+constexpr int kBP = 64;   // rows per tile
+constexpr double kG = 1.0 / 8192.0;          // g = 2^-13 (accumulation-error allowance, see header)
+constexpr double kUp = 1.0 + 1.0 / 1099511627776.0;  // 1 + 2^-40: covers the f64 rounding of the norm sums
+
+// ---------------------------------------------------------------------------
+// bf16 helpers on raw bits (host of the proofs above: every rounding direction is explicit)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf_rne(float x) {  // finite x
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf_f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ float f_down(double x) {  // largest float <= x (x >= 0, finite, < 2^127)
+    float f = (float)x;
+    if ((double)f > x) f = __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
+__device__ __forceinline__ float f_up(double x) {  // smallest float >= x (x >= 0)
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+__device__ __forceinline__ uint16_t bf_trunc(float x) { return (uint16_t)(__float_as_uint(x) >> 16); }  // x >= 0
+__device__ __forceinline__ uint16_t bf_up(float x) {  // x >= 0: smallest bf16 >= x
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u >> 16) + ((u & 0xFFFFu) ? 1u : 0u));
+}
+
+// One thread per (padded) corpus row: bf16 row + the five extra columns, written into the tile image.
+// img: [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
+__global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, size_t n, int dim, size_t ld, int KS,
+                                        uint16_t *__restrict__ img, size_t n_rows_img, uint32_t *__restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_img) return;
+    const int CP = 2 * KS + 1;
+    uint16_t *row = img + ((r / kBP) * (size_t)kBP + (r % kBP)) * (size_t)CP * 8;
+    const int E = 16 * (KS - 1);
+    for (int k = 0; k < CP * 8; ++k) row[k] = 0;
+    if (r >= n) {
+        row[E] = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+        return;
+    }
+    double pn = 0.0, en = 0.0, hn = 0.0;
+    bool finite = true;
+    const float *src = P + r * ld;
+    for (int k = 0; k < dim; ++k) {
+        const float x = src[k];
+        finite = finite && (fabsf(x) < 1.0e30f);  // also false for NaN
+        const uint16_t hb = (fabsf(x) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(x);  // 2^-60
+        const float xh = bf_f(hb);
+        row[k] = hb;
+        pn += (double)x * (double)x;
+        const double e = (double)x - (double)xh;
+        en += e * e;
+        hn += (double)xh * (double)xh;
+    }
+    if (!finite || !(pn < 1.2676506002282294e30)) {  // 2^100
+        atomicOr(bad, 1u);
+        row[E] = 0x7F80u;
+        return;
+    }
+    // |p|^2 (1 - g), rounded down, in three truncated bf16 pieces
+    double rem = pn * (1.0 - kG) / kUp;
+    const uint16_t h0 = bf_trunc(f_down(rem));
+    rem -= (double)bf_f(h0);
+    const uint16_t h1 = bf_trunc(f_down(rem));
+    rem -= (double)bf_f(h1);
+    const uint16_t h2 = bf_trunc(f_down(rem));
+    row[E + 0] = h0;
+    row[E + 1] = h1;
+    row[E + 2] = h2;
+    const double e_n = sqrt(en) * kUp, h_n = sqrt(hn) * kUp, p_n = sqrt(pn) * kUp;
+    row[E + 3] = bf_up(f_up((2.0 * e_n + 2.0 * kG * h_n) * (1.0 + 2.0 * kG)));
+    row[E + 4] = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
+}
+
+// One thread per (padded) query: bf16 B row [K] (chunk c at 8c), |q|^2 rounded down (f64), flag.
+__global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, size_t nq, size_t nq_pad, int dim, size_t ld,
+                                         int KS, uint16_t *__restrict__ B, double *__restrict__ qn,
+                                         uint32_t *__restrict__ qbad) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    const int K = 16 * KS, E = 16 * (KS - 1);
+    uint16_t *row = B + q * (size_t)K;
+    for (int k = 0; k < K; ++k) row[k] = 0;
+    double s = 0.0, en = 0.0, hn = 0.0;
+    bool finite = true;
+    if (q < nq) {
+        const float *src = Q + q * ld;
+        for (int k = 0; k < dim; ++k) {
+            const float x = src[k];
+            finite = finite && (fabsf(x) < 1.0e30f);
+            const uint16_t hb = (fabsf(x) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(x);
+            const float xh = bf_f(hb);
+            row[k] = bf_rne(-2.0f * xh);  // exact: a power-of-two multiple of a bf16 value
+            s += (double)x * (double)x;
+            const double e = (double)x - (double)xh;
+            en += e * e;
+            hn += (double)xh * (double)xh;
+        }
+    }
+    const bool ok = finite && (s < 1.2676506002282294e30);
+    row[E + 0] = 0x3F80u;  // 1.0
+    row[E + 1] = 0x3F80u;
+    row[E + 2] = 0x3F80u;
+    if (ok) {
+        row[E + 3] = (uint16_t)(bf_up(f_up(sqrt(hn) * kUp)) | 0x8000u);  // -Aq
+        row[E + 4] = (uint16_t)(bf_up(f_up(sqrt(en) * kUp)) | 0x8000u);  // -Cq
+    } else {
+        for (int k = 0; k < dim; ++k) row[k] = 0;  // keep the arithmetic finite; the query is re-run exactly
+    }
+    qn[q] = ok ? s / kUp : 0.0;
+    qbad[q] = ok ? 0u : 1u;
+}
+
+// ---------------------------------------------------------------------------
+// compaction of one query's buffer (<= 64*M entries in HBM) by its wave: keep the kp smallest under
+// (key, row); returns the kp-th key T and the new count (wave-uniform).  Same radix select as
+// compact_query (topk_buffer.h) but the bookkeeping goes back to registers.
+// ---------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, int lane, uint32_t &T_out,
+                                           uint32_t &n_out) {
+    uint32_t key[M], ix[M];
+    bool valid[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const uint32_t slot = m * 64 + lane;
+        valid[m] = slot < n;
+        uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (valid[m]) e = ce[slot];
+        key[m] = e.x;
+        ix[m] = e.y;
+    }
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        uint32_t c = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) c += (uint32_t)__popcll(__ballot(valid[m] && key[m] < cand));
+        if (c < kp) T = cand;
+    }
+    uint32_t n_less = 0, n_eq = 0;
+    bool sel[M], eq[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        sel[m] = valid[m] && key[m] < T;
+        eq[m] = valid[m] && key[m] == T;
+        n_less += (uint32_t)__popcll(__ballot(sel[m]));
+        n_eq += (uint32_t)__popcll(__ballot(eq[m]));
+    }
+    const uint32_t need_eq = kp - n_less;
+    uint32_t row_cut = 0xFFFFFFFFu;
+    if (n_eq > need_eq) {
+        uint32_t I = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = I | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) c += (uint32_t)__popcll(__ballot(eq[m] && ix[m] < cand));
+            if (c < need_eq) I = cand;
+        }
+        row_cut = I;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t pos = 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const bool keep = sel[m] || (eq[m] && ix[m] <= row_cut);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) ce[pos + (uint32_t)__popcll(mask & lt)] = make_uint2(key[m], ix[m]);
+        pos += (uint32_t)__popcll(mask);
+    }
+    T_out = T;
+    n_out = pos;
+}
+
+// KS-step chain of one 32-row block against the wave's two query blocks, while the VALU takes the
+// minimum of the OTHER block's bounds (r0, r1) in the matrix pipe's shadow.  The first kLA fragments
+// were read by the caller right behind the barrier; fragment ks + kLA is requested at step ks.
+// EMB: the register number i replaces the low four mantissa bits of bound i before the minimum is taken (one
+// v_and_or_b32 each), so the minimum itself says which register -- i.e. which row -- it came from, and the
+// rare path needs no search.  The filter then works on these tagged values throughout (comparison, stored key,
+// threshold); they differ from the bounds by less than 2^-19 relative, which the proof in select.hip subtracts.
+constexpr int kLA = 3;
+template <int KS, bool EMB>
+__device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
+                                         const bf16x8 (&b1)[KS], f32x16 &w0, f32x16 &w1, f32x16 &r0, f32x16 &r1,
+                                         float &m0, float &m1) {
+    bf16x8 f[KS];
+#pragma unroll
+    for (int i = 0; i < kLA && i < KS; ++i) f[i] = pre[i];
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + kLA < KS) f[ks + kLA] = *reinterpret_cast<const bf16x8 *>(arow + 32 * (ks + kLA));
+        w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : z, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : z, 0, 0, 0);
+        if (ks == 0) {
+            if (EMB) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    r0[i] = __uint_as_float((__float_as_uint(r0[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                    r1[i] = __uint_as_float((__float_as_uint(r1[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                }
+            }
+            float x = r0[0], y = r1[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                x = fminf(x, r0[i]);
+                y = fminf(y, r1[i]);
+            }
+            m0 = x;
+            m1 = y;
+        }
+    }
+}
+
+// append this lane's survivors of one (32-row block, query block) and compact the buffers that filled up.
+// cnt is the fill count of the lane's query (identical in lanes j and j+32, which hold different rows).
+// ns counts the vector-memory instructions this wave has issued since its last LDS-DMA (wave-uniform): the
+// wait in front of the tile barrier must cover the DMA but not these younger stores (see bf_wait_dma).
+template <int M>
+__device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
+                                        int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk, uint32_t &ns) {
+#ifdef PN_DIAG_BF_NOSLOW  // timing-only build: results are wrong
+    asm volatile("" ::"v"(acc[0]), "v"(tau));
+#ifdef PN_DIAG_BF_FAKESLOW
+    __builtin_amdgcn_s_sleep(PN_DIAG_BF_FAKESLOW);  // a rare path of 64 * N cycles that touches nothing
+#endif
+    return;
+#endif
+    constexpr uint32_t CAP = 64u * M;
+    if (lane == 0) BF_COUNT(0, 1);
+#ifdef PN_DIAG_BF_COUNT
+    const unsigned long long t0_ = bf_stamp();
+#endif
+    const uint32_t rowb = row0 + 4 * h;
+    uint32_t np = 0;  // survivors of this lane (acc holds TAGGED bounds, mn their minimum)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) np += acc[r] < tau ? 1u : 0u;
+#ifdef PN_DIAG_BF_COUNT
+    const unsigned long long t1_ = bf_stamp();
+#endif
+    if (!__any(np > 1u)) {
+        // steady state: a lane has at most one survivor, its minimum, whose tag is the register number
+        const bool p = mn < tau;
+        const uint32_t pp = p ? 1u : 0u;
+        const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
+        const uint32_t other = h ? sw[0] : sw[1];  // the other half's lane of the same query
+        if (p) {
+            const uint32_t r = __float_as_uint(mn) & 15u;
+            const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
+            // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
+            ceq[o] = make_uint2(f2s(mn), rowb + (r & 3u) + 8u * (r >> 2));
+        }
+        BF_COUNT(1, pp);
+        cnt += pp + other;
+        ns += 1;
+    } else {
+        // general case: one short block per register that holds a survivor in SOME lane
+        uint32_t wor = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wor |= (__any(acc[r] < tau) ? 1u : 0u) << r;
+        while (wor) {
+            const int r = __builtin_ctz(wor);
+            wor &= wor - 1;
+            const float v = acc[r];  // r is wave-uniform: indexed register read
+            const bool p = v < tau;
+            const uint32_t pp = p ? 1u : 0u;
+            const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
+            const uint32_t other = h ? sw[0] : sw[1];
+            if (p) {
+                const uint32_t o = cnt + (h ? other : 0u);
+                ceq[o] = make_uint2(f2s(v), rowb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+            }
+            BF_COUNT(1, pp);
+            cnt += pp + other;
+            ns += 1;
+        }
+    }
+#ifdef PN_DIAG_BF_COUNT
+    const unsigned long long t2_ = bf_stamp();
+#endif
+    unsigned long long need = __ballot(h == 0 && cnt > CAP - 32);
+    if (need) {
+        // the entries were stored by both halves of the wave: they must have left before they are read back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ns = 0;
+        do {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+            uint32_t T, nn;
+            if (lane == 0) BF_COUNT(2, 1);
+            bf_compact<M>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
+            if (jq == j) {
+                tau = s2f(T);
+                cnt = nn;
+            }
+        } while (need);
+        ns += 16;  // at least: forces the plain wait at the next barrier
+    }
+#ifdef PN_DIAG_BF_COUNT
+    {
+        const unsigned long long t3_ = bf_stamp();
+        if (lane == 0) {
+            BF_COUNT(3, t3_ - t0_);
+            BF_COUNT(5, t1_ - t0_);
+            BF_COUNT(6, t2_ - t1_);
+            BF_COUNT(7, t3_ - t2_);
+        }
+    }
+#endif
+}
+
+// Wait until this wave's LDS-DMA of the next tile has landed WITHOUT waiting for the (younger) candidate
+// stores: vector-memory operations of a wave retire in order, so "at most ns outstanding" is enough when ns
+// store instructions were issued after the DMA.  s_waitcnt takes an immediate: 16 cases, larger counts wait
+// for a few of the oldest stores as well.
+__device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
+    switch (ns < 15u ? ns : 15u) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+}
+
+// cand: [nseg][nq_pad][64*M] (key, row) pairs; ccnt/ctau: [nseg][nq_pad], pre-initialised to 0 / sortable(+inf)
+template <int KS, int M>
+__global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
+                                                             const u32x4 *__restrict__ Bq, uint32_t q_tiles,
+                                                             uint32_t kp, uint2 *__restrict__ cand,
+                                                             uint32_t *__restrict__ ccnt,
+                                                             uint32_t *__restrict__ ctau, size_t nq_pad,
+                                                             uint32_t split, uint32_t seg_per_part,
+                                                             uint32_t scout_max) {
+    constexpr int C = 2 * KS, CP = C + 1;
+    constexpr uint32_t CAP = 64u * M;
+    constexpr int TB = kBP * CP * 16;  // bytes per tile image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    char *tiles = reinterpret_cast<char *>(smem_raw);  // [2][TB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jq = lane & 31, h = lane >> 5;
+
+    // Work list: (query tile, row part, tile within the part) in that order; `split` row parts per query tile
+    // (1 unless the host wants more, shorter segments per query: see bf16_slots in index.hip), tps tiles each
+    // (the last part may be shorter: its tail units are empty).  Workgroup w owns the contiguous slice
+    // [w U / W, (w+1) U / W) and walks it in runs that stay inside one (query tile, part).
+    const uint32_t tps = (n_tiles + split - 1) / split;
+    const unsigned long long U = (unsigned long long)q_tiles * split * tps;
+    const unsigned long long W = gridDim.x, w = blockIdx.x;
+    unsigned long long u0 = w * U / W;
+    const unsigned long long u1 = (w + 1) * U / W;
+
+    auto dma_tile = [&](uint32_t rt, int buf) {
+        const char *src = img + (size_t)rt * (size_t)TB + lane * 16;
+        char *dst = tiles + buf * TB;
+#pragma unroll
+        for (int i0 = 0; i0 < CP; i0 += 4) {
+            const int i = i0 + wave;
+            if (i < CP)
+                __builtin_amdgcn_global_load_lds((glb_void_b *)(src + i * 1024), (lds_void_b *)(dst + i * 1024), 16, 0,
+                                                 0);
+        }
+    };
+
+    while (u0 < u1) {
+        const unsigned long long v = u0 / tps;  // (query tile, part)
+        const uint32_t qt = (uint32_t)(v / split), part = (uint32_t)(v % split);
+        const unsigned long long v_begin = v * tps, v_end = v_begin + tps;
+        const unsigned long long run_end = u1 < v_end ? u1 : v_end;
+        const uint32_t rt0 = part * tps + (uint32_t)(u0 - v_begin);
+        uint32_t rt1 = part * tps + (uint32_t)(run_end - v_begin);
+        if (rt1 > n_tiles) rt1 = n_tiles;
+        if (rt0 >= rt1) {  // empty tail of the last part
+            u0 = run_end;
+            continue;
+        }
+        // ordinal of this workgroup among those touching (query tile, part) v
+        unsigned long long wf = v_begin * W / U;
+        while ((wf + 1) * U / W <= v_begin) ++wf;
+        while (wf > 0 && wf * U / W > v_begin) --wf;
+        const uint32_t seg = part * seg_per_part + (uint32_t)(w - wf);
+        const size_t q0 = (size_t)qt * kBQ + (size_t)wave * 64;  // first query of this wave
+        const size_t cell0 = (size_t)seg * nq_pad + q0;          // its (segment, query) cell
+
+        // ---- per-run state: B fragments, thresholds and counts in registers
+        bf16x8 b0[KS], b1[KS];
+        {
+            const u32x4 *br0 = Bq + (q0 + jq) * (size_t)C + h;
+            const u32x4 *br1 = br0 + (size_t)32 * C;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 v0 = br0[2 * ks], v1 = br1[2 * ks];
+                b0[ks] = __builtin_bit_cast(bf16x8, v0);
+                b1[ks] = __builtin_bit_cast(bf16x8, v1);
+            }
+        }
+        float tau0 = __uint_as_float(0x7F800000u), tau1 = tau0;
+        uint32_t cnt0 = 0, cnt1 = 0;
+
+        // ---- scout pass.  A buffer that starts from tau = +inf admits ~k' ln(n/k') rows before its threshold
+        // has converged, and with 2048 waves x 64 buffers warming up at once those appends, not the MFMAs, set
+        // the kernel's time.  So the first t tiles of the run are first contracted WITHOUT buffers: each lane
+        // keeps the 4 smallest of its block minima (16 rows each); the 4th smallest, over both lane halves, is
+        // the starting threshold of the real pass (about the 1e-3 quantile of the segment's bounds: ~30x fewer
+        // rows pass it than pass a cold buffer, and it is far above the k-th neighbour's bound).  ANY starting
+        // value is valid -- rows are only ever dropped against the threshold that is finally reported -- a
+        // threshold that turns out too low merely sends the query to the next tier.
+        const uint32_t run_len = rt1 - rt0;
+#ifdef PN_DIAG_BF_NOSCOUT
+        const uint32_t t_scout = 0;
+#else
+        uint32_t t_scout = run_len / 16u < 64u ? run_len / 16u : 64u;
+        if (t_scout > scout_max) t_scout = scout_max;  // host: keeps the scouted rows' share of true neighbours tiny
+        if (t_scout < 4u) t_scout = 0;
+#endif
+        if (t_scout) {
+            const float inf = __uint_as_float(0x7F800000u);
+            float s0[4] = {inf, inf, inf, inf}, s1[4] = {inf, inf, inf, inf};
+            auto insert4 = [](float (&l)[4], float x) {
+                float t = fmaxf(l[0], x);
+                l[0] = fminf(l[0], x);
+                float u = fmaxf(l[1], t);
+                l[1] = fminf(l[1], t);
+                t = fmaxf(l[2], u);
+                l[2] = fminf(l[2], u);
+                l[3] = fminf(l[3], t);
+            };
+            __syncthreads();
+            dma_tile(rt0, 0);
+            __syncthreads();
+            f32x16 x00, x01, x10, x11;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x00[r] = inf; x01[r] = inf; x10[r] = inf; x11[r] = inf; }
+            int cs = 0;
+            for (uint32_t rt = rt0; rt < rt0 + t_scout; ++rt, cs ^= 1) {
+                const char *tb = tiles + cs * TB;
+                const char *arow0 = tb + (jq * CP + h) * 16;
+                const char *arow1 = arow0 + 32 * CP * 16;
+                bf16x8 pre0[kLA], pre1[kLA];
+#pragma unroll
+                for (int i = 0; i < kLA; ++i) {
+                    pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
+                    pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
+                }
+                if (rt + 1 < rt0 + t_scout) dma_tile(rt + 1, cs ^ 1);
+                float m0, m1;
+                bf_chain<KS, false>(arow0, pre0, b0, b1, x00, x01, x10, x11, m0, m1);
+                insert4(s0, m0);
+                insert4(s1, m1);
+                bf_chain<KS, false>(arow1, pre1, b0, b1, x10, x11, x00, x01, m0, m1);
+                insert4(s0, m0);
+                insert4(s1, m1);
+                __syncthreads();
+            }
+            float m0 = x10[0], m1 = x11[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                m0 = fminf(m0, x10[i]);
+                m1 = fminf(m1, x11[i]);
+            }
+            insert4(s0, m0);
+            insert4(s1, m1);
+            tau0 = fminf(s0[3], __shfl_xor(s0[3], 32));
+            tau1 = fminf(s1[3], __shfl_xor(s1[3], 32));
+        }
+        uint2 *ce_blk0 = cand + cell0 * CAP;              // query block 0: 32 buffers
+        uint2 *ce_blk1 = ce_blk0 + (size_t)32 * CAP;      // query block 1
+        uint2 *ceq0 = ce_blk0 + (size_t)jq * CAP, *ceq1 = ce_blk1 + (size_t)jq * CAP;
+        uint32_t ns = 0;
+
+        // ---- prologue: first tile -> LDS[0]
+        __syncthreads();  // previous run's readers are done with both buffers
+        dma_tile(rt0, 0);
+        __syncthreads();  // carries the vmcnt(0)
+
+        // Pipeline per tile rt (two 32-row blocks, accumulators a0x / a1x for the two query blocks x):
+        //   [barrier passed: tile rt is in LDS]  first fragments of both blocks requested; DMA of tile rt+1
+        //   rare path for block 0 of tile rt-1 (minima taken during the previous chain)
+        //   chain(block 0) -> a0x while the VALU takes the minima of a1x (block 1 of tile rt-1); its rare path
+        //   chain(block 1) -> a1x while the VALU takes the minima of a0x; barrier
+        f32x16 a00, a01, a10, a11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // finite: a tag on +inf would make a NaN
+            a00[r] = 3.0e38f;
+            a01[r] = 3.0e38f;
+            a10[r] = 3.0e38f;
+            a11[r] = 3.0e38f;
+        }
+        float p0 = __uint_as_float(0x7F800000u), p1 = p0;  // minima of a00 / a01 still to be filtered
+        int cur = 0;
+        for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1) {
+            const char *tb = tiles + cur * TB;
+            const char *arow0 = tb + (jq * CP + h) * 16;
+            const char *arow1 = arow0 + 32 * CP * 16;
+            bf16x8 pre0[kLA], pre1[kLA];
+#pragma unroll
+            for (int i = 0; i < kLA; ++i) {
+                pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
+                pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
+            }
+            if (rt + 1 < rt1) dma_tile(rt + 1, cur ^ 1);
+            ns = 0;
+            if (__any(p0 < tau0 || p1 < tau1)) {
+                const uint32_t row0 = (rt - 1) * kBP;
+                if (__any(p0 < tau0)) bf_slow<M>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                if (__any(p1 < tau1)) bf_slow<M>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            }
+            float m0, m1;
+            bf_chain<KS, true>(arow0, pre0, b0, b1, a00, a01, a10, a11, m0, m1);
+            if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
+            if (__any(m0 < tau0 || m1 < tau1)) {
+                const uint32_t row0 = (rt - 1) * kBP + 32;
+                if (__any(m0 < tau0)) bf_slow<M>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                if (__any(m1 < tau1)) bf_slow<M>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            }
+            bf_chain<KS, true>(arow1, pre1, b0, b1, a10, a11, a00, a01, p0, p1);
+            // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
+#if defined(PN_DIAG_BF_COUNT)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the diagnostic atomics are not counted in ns
+#elif !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
+            bf_wait_dma(ns);
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        {  // drain: both blocks of the last tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                a10[i] = __uint_as_float((__float_as_uint(a10[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                a11[i] = __uint_as_float((__float_as_uint(a11[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+            }
+            float m0 = a10[0], m1 = a11[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                m0 = fminf(m0, a10[i]);
+                m1 = fminf(m1, a11[i]);
+            }
+            uint32_t row0 = (rt1 - 1) * kBP;
+            if (__any(p0 < tau0)) bf_slow<M>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+            if (__any(p1 < tau1)) bf_slow<M>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            row0 += 32;
+            if (__any(m0 < tau0)) bf_slow<M>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+            if (__any(m1 < tau1)) bf_slow<M>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+        }
+        // ---- end of run: at most kp candidates per query stay; publish count and threshold
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long need = __ballot(h == 0 && cnt0 > kp);
+            while (need) {
+                const int j = __builtin_ctzll(need);
+                need &= need - 1;
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, j);
+                uint32_t T, nn;
+                bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
+                if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
+            }
+            need = __ballot(h == 0 && cnt1 > kp);
+            while (need) {
+                const int j = __builtin_ctzll(need);
+                need &= need - 1;
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, j);
+                uint32_t T, nn;
+                bf_compact<M>(ce_blk1 + (size_t)j * CAP, cj, kp, lane, T, nn);
+                if (jq == j) { tau1 = s2f(T); cnt1 = nn; }
+            }
+#if defined(PN_DIAG_BF_NOSTORE) || defined(PN_DIAG_BF_NOSLOW)
+            cnt0 = 0;  // timing-only builds: the buffers hold no valid rows
+            cnt1 = 0;
+#endif
+            if (h == 0) {
+                ccnt[cell0 + jq] = cnt0;
+                ctau[cell0 + jq] = f2s(tau0);
+                ccnt[cell0 + 32 + jq] = cnt1;
+                ctau[cell0 + 32 + jq] = f2s(tau1);
+            }
+        }
+        u0 = run_end;
+    }
+}
+
+#ifdef PN_DIAG_BF_COUNT
+extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfdbg), sizeof(z)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_bfdbg), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int bf16_ks_for(int dim) { return (dim + 15) / 16 + 1; }
+bool bf16_supported(int dim) { return dim >= 1 && dim <= 128; }
+size_t bf16_image_bytes(size_t n, int dim) {
+    const size_t n_tiles = (n + kBP - 1) / kBP;
+    return n_tiles * (size_t)kBP * (size_t)(2 * bf16_ks_for(dim) + 1) * 16;
+}
+size_t bf16_query_bytes(size_t nq_pad, int dim) { return nq_pad * (size_t)bf16_ks_for(dim) * 32; }
+#ifdef PN_DIAG_BF_CAP
+int bf16_cap_for(int kp) { return kp + 32 <= PN_DIAG_BF_CAP ? PN_DIAG_BF_CAP : 256; }
+#else
+// a buffer is compacted once fewer than 32 free slots remain; a compaction is also what refreshes the threshold,
+// so small k' take the small buffer (measured: k' = 12, 64 slots 4.7 ms vs 128 slots 5.2 ms on the headline config)
+int bf16_cap_for(int kp) { return kp <= 16 ? 64 : kp <= 64 ? 128 : 256; }
+#endif
+int bf16_query_tile() { return kBQ; }
+
+hipError_t launch_bf16_pack_corpus(const float *P, size_t n, int dim, size_t ld, void *img, uint32_t *bad,
+                                   hipStream_t s) {
+    const size_t rows = (n + kBP - 1) / kBP * kBP;
+    hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, n, dim, ld,
+                       bf16_ks_for(dim), static_cast<uint16_t *>(img), rows, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, int dim, size_t ld, void *B, double *qn,
+                                    uint32_t *qbad, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, nq, nq_pad,
+                       dim, ld, bf16_ks_for(dim), static_cast<uint16_t *>(B), qn, qbad);
+    return hipGetLastError();
+}
+
+template <int KS, int M>
+static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
+                                const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
+                                hipStream_t s) {
+    const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
+    auto kern = bf16_filter_kernel<KS, M>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,
+                       static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,
+                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max);
+    return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
+                                const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
+                                hipStream_t s) {
+    switch (cb.cap) {
+        case 64: return launch_bf16_t<KS, 1>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
+        case 128: return launch_bf16_t<KS, 2>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
+        case 256: return launch_bf16_t<KS, 4>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// cb: keys = (key, row) pairs [nseg][nq_pad][cap] (cb.idx = keys + 1, cb.idx_stride = 2), cap = bf16_cap_for(kp);
+// cnt/tau PRE-INITIALISED to 0 / sortable(+inf);
+// nseg >= mfma_v2_max_segments(nq_pad / 256, n_wg)
+int bf16_segments(size_t q_tiles, int n_wg, int split) {
+    return split * mfma_v2_max_segments(q_tiles * (size_t)split, n_wg);
+}
+
+hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
+                              int split, int scout_max, hipStream_t s) {
+    if (!bf16_supported(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
+        cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0)
+        return hipErrorInvalidValue;
+    const uint32_t n_tiles = (uint32_t)((n + kBP - 1) / kBP);
+    const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kBQ);
+    if ((uint32_t)split > n_tiles) return hipErrorInvalidValue;
+    const uint32_t spp = (uint32_t)mfma_v2_max_segments((size_t)q_tiles * split, n_wg);
+    if (cb.nseg < (int)(spp * split)) return hipErrorInvalidValue;
+    const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
+    switch (bf16_ks_for(dim)) {
+        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// debug / test entry: L'(q, p) for every pair of a small problem, straight from the MFMA (one wave per
+// 32 x 32 block), so tests can check L' <= |q-p|^2 - |q|^2 against f64 and measure the accumulation error.
+template <int KS>
+__global__ __launch_bounds__(64) void bf16_bound_kernel(const char *__restrict__ img, const u32x4 *__restrict__ Bq,
+                                                        uint32_t n_rows, uint32_t nq, float *__restrict__ out) {
+    constexpr int C = 2 * KS, CP = C + 1;
+    const int lane = threadIdx.x, jq = lane & 31, h = lane >> 5;
+    const uint32_t rb = blockIdx.x, qb = blockIdx.y;  // 32-row block, 32-query block
+    const uint32_t row = rb * 32 + jq;
+    const char *arow = img + ((size_t)(row / kBP) * kBP * CP + (size_t)(row % kBP) * CP + h) * 16;
+    const u32x4 *br = Bq + ((size_t)qb * 32 + jq) * C + h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 av = *reinterpret_cast<const u32x4 *>(arow + 32 * ks);
+        const u32x4 bv = br[2 * ks];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                      acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const uint32_t q = qb * 32 + jq;
+        if (i < n_rows && q < nq) out[(size_t)q * n_rows + i] = acc[r];
+    }
+}
+
+hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
+                             hipStream_t s) {
+    // img covers round_up(n_rows, 64) rows and B round_up(nq, 32) queries at least
+    const dim3 grid((unsigned)((n_rows + 31) / 32), (unsigned)((nq + 31) / 32));
+    const char *im = static_cast<const char *>(img);
+    const u32x4 *b = static_cast<const u32x4 *>(B);
+#define PN_BOUND_CASE(K)                                                                                       \
+    case K:                                                                                                    \
+        hipLaunchKernelGGL(bf16_bound_kernel<K>, grid, dim3(64), 0, s, im, b, (uint32_t)n_rows, (uint32_t)nq, out); \
+        break;
+    switch (bf16_ks_for(dim)) {
+        PN_BOUND_CASE(2) PN_BOUND_CASE(3) PN_BOUND_CASE(4) PN_BOUND_CASE(5) PN_BOUND_CASE(6) PN_BOUND_CASE(7)
+        PN_BOUND_CASE(8) PN_BOUND_CASE(9)
+        default: return hipErrorInvalidValue;
+    }
+#undef PN_BOUND_CASE
+    return hipGetLastError();
+}
+
+}  // namespace pn

@@ -103,6 +103,9 @@ struct pn_index {
     void *d_pts = nullptr;   // [n_pad][ld], zero padded
     float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
     bool mfma_ok = false;
+    void *d_img = nullptr;   // f32, D <= 128: bf16 tile images of the corpus (bf16_filter.hip)
+    bool bf16_ok = false;
+    int bf16_level = 0;      // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
     int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
     hipStream_t stream = nullptr;
     // options
@@ -116,6 +119,7 @@ struct pn_index {
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
     mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
+    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc;  // bf16 tier
     mutable pn_stats stats{};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
@@ -184,6 +188,23 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         HIPCHK(hipStreamSynchronize(s));
         (void)hipFree(d_flag);
         ix->mfma_ok = (h_flag == 0) && mfma_supported((int)ix->dim, ix->ld) && ix->n < 0xFFFFFFF0ull;
+        ix->bf16_ok = false;
+        if (bf16_supported((int)ix->dim) && ix->n < 0xFFFFFFF0ull && ix->n >= 64) {
+            HIPCHK(hipMalloc(&ix->d_img, bf16_image_bytes(ix->n, (int)ix->dim)));
+            uint32_t *d_bad = nullptr;
+            HIPCHK(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s));
+            HIPCHK(launch_bf16_pack_corpus((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, ix->d_img, d_bad, s));
+            uint32_t h_bad = 0;
+            HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            (void)hipFree(d_bad);
+            ix->bf16_ok = (h_bad == 0);
+            if (!ix->bf16_ok) {
+                (void)hipFree(ix->d_img);
+                ix->d_img = nullptr;
+            }
+        }
     } else {
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -302,9 +323,12 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ix->w_q, &ix->w_qnorm, &ix->w_keys, &ix->w_idx, &ix->w_cnt, &ix->w_tau, &ix->w_flags,
                       &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
-                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo};
+                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo,
+                      &ix->w_bq, &ix->w_qn, &ix->w_qbad, &ix->w_bflags, &ix->w_gq, &ix->w_gidx, &ix->w_gdist,
+                      &ix->w_gsel, &ix->w_bmisc};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
+    if (ix->d_img) (void)hipFree(ix->d_img);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
     hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3};
     for (hipEvent_t e : evs)
@@ -321,7 +345,7 @@ extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
     out->elem_bytes = ix->elem_bytes;
     out->device = ix->device;
     out->mfma_eligible = ix->mfma_ok ? 1 : 0;
-    out->reserved = 0;
+    out->bf16_eligible = ix->bf16_ok ? 1 : 0;
     return PN_OK;
 }
 
@@ -330,10 +354,13 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
     std::lock_guard<std::mutex> lk(ix->mu);
     switch (option) {
         case PN_OPT_ENGINE:
-            if (value < PN_ENGINE_AUTO || value > PN_ENGINE_MFMA) return fail(PN_ERR_INVALID, "bad engine %lld", (long long)value);
+            if (value < PN_ENGINE_AUTO || value > PN_ENGINE_BF16) return fail(PN_ERR_INVALID, "bad engine %lld", (long long)value);
+            if (value == PN_ENGINE_BF16 && !ix->bf16_ok)
+                return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (f64, D > 128, fewer than 64 rows or out-of-range values)");
             if (value == PN_ENGINE_MFMA && !ix->mfma_ok)
                 return fail(PN_ERR_UNSUPPORTED, "the MFMA filter cannot serve this index (f64, non-finite norms or unsupported shape)");
             ix->engine = (int)value;
+            ix->bf16_level = 0;
             return PN_OK;
         case PN_OPT_SEGMENTS:
             if (value < 0 || value > 4096) return fail(PN_ERR_INVALID, "bad segment count");
@@ -499,6 +526,58 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
     return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
 
+// Plan of the bf16 tier for one call.  R ~ 2k rows have a bf16 bound below the k-th neighbour's distance on
+// benign data (the bound is loose by a few percent of the distance spread).  The proof needs every segment's
+// k'-th bound to clear that distance, i.e. k' above the number of those R rows that fall into one segment:
+//   level 0 (default): rows in arbitrary order -- a segment holds Poisson(R / segments) of them, k' is that mean
+//            plus six standard deviations; a query tile served by fewer than 4 workgroups is split into row
+//            parts so that small buffers suffice;
+//   level 1: all R rows may sit in one segment (corpus sorted by cluster): k' = R + 6 sqrt(R);
+//   level 2: tier off.
+// A call that had to hand more than 1/16 of its queries to the next tier raises the index's level (sticky).
+struct Bf16Plan {
+    int n_wg, split, nseg, kp, cap, scout_max;
+    bool ok;
+};
+static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
+    Bf16Plan p{};
+    const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
+    size_t n_wg = 2 * (size_t)ix->n_cu;
+    size_t cap_wg = q_tiles * 32;  // at most ~32 workgroups per query tile, at least ~32 row tiles each
+    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    if (by_work < cap_wg) cap_wg = by_work;
+    if (ix->opt_segments > 0 && q_tiles * (size_t)ix->opt_segments < cap_wg) cap_wg = q_tiles * (size_t)ix->opt_segments;
+    if (cap_wg < 1) cap_wg = 1;
+    if (n_wg > cap_wg) n_wg = cap_wg;
+    p.n_wg = (int)n_wg;
+    const double R = kout < 32 ? 2.0 * (double)kout + 6.0 : 2.0 * (double)kout;
+    size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
+    if (per_tile < 1) per_tile = 1;
+    auto kp_for = [&](int split) -> double {
+        if (ix->filter_slots > 0) return (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
+        if (ix->bf16_level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
+        const double per = R / (double)(per_tile * (size_t)split);
+        const double v = per + 6.0 * std::sqrt(per) + 4.0;
+        return v < 8.0 ? 8.0 : v;
+    };
+    // split the rows of a query tile into parts only while one buffer would need more than 128 slots
+    // (every part pays its own warm-up), and keep parts of at least 256 tiles
+    p.split = 1;
+    if (ix->bf16_level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0)
+        while (p.split < 8 && kp_for(p.split) > 96.0 && r_tiles / (size_t)(2 * p.split) >= 256) p.split *= 2;
+    const double kp = kp_for(p.split);
+    p.kp = (int)std::ceil(kp);
+    p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256;
+    p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
+    p.nseg = bf16_segments(q_tiles, p.n_wg, p.split);
+    // scouted rows should hold < 0.1 of the R relevant rows in expectation: tiles <= N / (10 R) / 64
+    const double sm = (double)r_tiles / (10.0 * R);
+    p.scout_max = sm > 64.0 ? 64 : (int)sm;
+    return p;
+}
+static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
+                    float *d_dist, hipStream_t s, bool mfma_fallback);
+
 template <typename T>
 static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
                              uint64_t *d_idx, T *d_dist, hipStream_t s) {
@@ -522,20 +601,25 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
     const size_t chunk = 1u << 18;
     for (size_t qs = 0; qs < nq; qs += chunk) {
         const size_t nqc = (nq - qs < chunk) ? nq - qs : chunk;
-        const size_t nq_pad = round_up(nqc, (size_t)128);  // query tiles are 64 (exact) or 128 (MFMA) rows
+        const size_t nq_pad = round_up(nqc, (size_t)256);  // query tiles are 64 (exact), 128 (MFMA) or 256 (bf16) rows
         PNCHK(ix->w_q.ensure(nq_pad * ix->ld * sizeof(T)));
         T *Qp = (T *)ix->w_q.p;
         HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
         uint64_t *oi = d_idx + qs * kout;
         T *od = d_dist + qs * kout;
-        bool use_mfma = false;
+        bool use_mfma = false, use_bf16 = false;
         if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
             // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
             use_mfma = mfma_slots(ix, kout, nq_pad) + 64 <= 256;
             if (ix->ld > 128 && mfma_slots(ix, kout, nq_pad) > 30) use_mfma = false;  // wide rows: LDS-buffer kernel only
             if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
         }
-        if (use_mfma)
+        if (sizeof(T) == 4 && ix->bf16_ok && dim_eff == ix->dim &&
+            (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8)))
+            use_bf16 = bf16_plan(ix, nq_pad, kout).ok;
+        if (use_bf16)
+            PNCHK(run_bf16(ix, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, s, use_mfma));
+        else if (use_mfma)
             PNCHK(run_mfma(ix, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, s));
         else
             PNCHK(run_exact<T>(ix, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, s, false, true));
@@ -620,7 +704,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_flags.p, d_nflag,
-                                    d_ncand, s));
+                                    d_ncand, nullptr, nullptr, s));
     struct { uint32_t nflag, qnonfinite; uint64_t ncand; } h{};
     HIPCHK(hipMemcpyAsync(&h, ix->w_misc.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -647,6 +731,80 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
         HIPCHK(launch_scatter_results_f32((const uint64_t *)ix->w_fidx.p, (const float *)ix->w_fdist.p,
                                           (const uint32_t *)ix->w_sel.p, (int)nf, (int)kout, d_idx, d_dist, s));
         ix->stats.fallback_queries += nf;
+    }
+    return PN_OK;
+}
+
+// bf16 filter -> exact re-rank -> verification -> f32 MFMA engine (or exact scan) for the unproven queries
+static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
+                    float *d_dist, hipStream_t s, bool mfma_fallback) {
+    const Bf16Plan plan = bf16_plan(ix, nq_pad, kout);
+    if (!plan.ok) return fail(PN_ERR_UNSUPPORTED, "bf16 tier cannot serve k = %zu", kout);
+    const int n_wg = plan.n_wg, cap = plan.cap, nseg = plan.nseg;
+    const size_t kp = (size_t)plan.kp;
+    const size_t cells = (size_t)nseg * nq_pad, slots = cells * (size_t)cap;
+    PNCHK(ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ix->w_qn.ensure(nq_pad * sizeof(double)));
+    PNCHK(ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_keys.ensure(slots * 2 * sizeof(uint32_t)));  // (key, row) pairs
+    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_bflags.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_bmisc.ensure(64));
+    uint32_t *d_nflag = (uint32_t *)ix->w_bmisc.p;
+    uint64_t *d_ncand = (uint64_t *)((char *)ix->w_bmisc.p + 8);
+    uint32_t *d_nsel = (uint32_t *)((char *)ix->w_bmisc.p + 16);
+    HIPCHK(hipMemsetAsync(ix->w_bmisc.p, 0, 64, s));
+    HIPCHK(launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+                                    (uint32_t *)ix->w_qbad.p, s));
+    CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_keys.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
+    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+    const bool prof = ix->profile;
+    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, plan.split,
+                              plan.scout_max, s));
+    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
+    HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
+                                    (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_bflags.p, d_nflag,
+                                    d_ncand, (const double *)ix->w_qn.p, (const uint32_t *)ix->w_qbad.p, s));
+    struct { uint32_t nflag, pad; uint64_t ncand; } h{};
+    HIPCHK(hipMemcpyAsync(&h, ix->w_bmisc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (prof) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        ix->stats.hot_ms += ms;
+        ix->stats.hot_launches += 1;
+    }
+    ix->stats.candidates += h.ncand;
+    if (h.nflag) {
+        // second tier for the unproven queries: the f32 MFMA filter (which has its own exact fallback)
+        const size_t nf = h.nflag;
+        const size_t nf_pad = round_up(nf, (size_t)256);
+        PNCHK(ix->w_gsel.ensure(nq * sizeof(uint32_t)));
+        PNCHK(ix->w_gq.ensure(nf_pad * ix->ld * sizeof(float)));
+        PNCHK(ix->w_gidx.ensure(nf * kout * sizeof(uint64_t)));
+        PNCHK(ix->w_gdist.ensure(nf * kout * sizeof(float)));
+        HIPCHK(hipMemsetAsync(ix->w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s));
+        HIPCHK(launch_compact_flags((const uint32_t *)ix->w_bflags.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_nsel, s));
+        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_gsel.p, (int)nf, (float *)ix->w_gq.p, s));
+        const bool prof_saved = ix->profile;
+        const_cast<pn_index *>(ix)->profile = 0;  // hot-kernel statistics describe the first tier only
+        int rc;
+        if (mfma_fallback)
+            rc = run_mfma(ix, (const float *)ix->w_gq.p, nf, nf_pad, kout, (uint64_t *)ix->w_gidx.p,
+                          (float *)ix->w_gdist.p, s);
+        else
+            rc = run_exact<float>(ix, (const float *)ix->w_gq.p, nf, nf_pad, (int)ix->dim, kout,
+                                  (uint64_t *)ix->w_gidx.p, (float *)ix->w_gdist.p, s, true, false);
+        const_cast<pn_index *>(ix)->profile = prof_saved;
+        if (rc != PN_OK) return rc;
+        HIPCHK(launch_scatter_results_f32((const uint64_t *)ix->w_gidx.p, (const float *)ix->w_gdist.p,
+                                          (const uint32_t *)ix->w_gsel.p, (int)nf, (int)kout, d_idx, d_dist, s));
+        ix->stats.fallback_queries += nf;
+        if (nf * 16 > nq && nq >= 64 && ix->filter_slots == 0 && ix->bf16_level < 2)
+            const_cast<pn_index *>(ix)->bf16_level += 1;  // this corpus defeats the current plan: widen it / turn the tier off
     }
     return PN_OK;
 }
@@ -730,6 +888,51 @@ extern "C" int pn_query_nearest_f32(const pn_index *ix, const float *q, size_t n
 extern "C" int pn_query_nearest_f64(const pn_index *ix, const double *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
                                     uint64_t *idx_out, double *dist_out) {
     return query_host_impl<double>(ix, q, nq, q_cols, q_stride, 1, idx_out, dist_out);
+}
+
+// diagnostic: the bf16 filter's lower bounds themselves (see the header)
+extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
+                                  size_t n_rows, float *bounds_out, double *qnorm_out) {
+    if (!ix || !q || !bounds_out) return fail(PN_ERR_INVALID, "NULL argument");
+    if (ix->elem_bytes != 4 || !ix->bf16_ok) return fail(PN_ERR_UNSUPPORTED, "index has no bf16 tier");
+    if (q_cols != ix->dim) return fail(PN_ERR_INVALID, "queries must have the index's dimension");
+    if (nq == 0 || n_rows == 0) return PN_OK;
+    if (n_rows > ix->n) n_rows = ix->n;
+    if (nq * n_rows > ((size_t)1 << 28)) return fail(PN_ERR_INVALID, "too many bounds requested");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    hipStream_t s = ix->stream;
+    float *d_q = nullptr, *d_out = nullptr;
+    int rc = upload_rows<float>(q, nq, q_cols, q_stride, &d_q);
+    do {
+        if (rc != PN_OK) break;
+        const size_t nq_pad = round_up(nq, (size_t)256);
+        rc = PN_ERR_DEVICE;
+        if (ix->w_q.ensure(nq_pad * ix->ld * sizeof(float)) != PN_OK ||
+            ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)) != PN_OK ||
+            ix->w_qn.ensure(nq_pad * sizeof(double)) != PN_OK || ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)) != PN_OK)
+            break;
+        if (hipMalloc((void **)&d_out, nq * n_rows * sizeof(float)) != hipSuccess) {
+            rc = fail(PN_ERR_NOMEM, "hipMalloc bounds failed");
+            break;
+        }
+        float *Qp = (float *)ix->w_q.p;
+        if (launch_pack_rows_f32(d_q, nq, ix->dim, q_cols, Qp, nq_pad, ix->ld, s) != hipSuccess ||
+            launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+                                     (uint32_t *)ix->w_qbad.p, s) != hipSuccess ||
+            launch_bf16_bound(ix->d_img, ix->w_bq.p, n_rows, nq, (int)ix->dim, d_out, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(bounds_out, d_out, nq * n_rows * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            (qnorm_out && hipMemcpy(qnorm_out, ix->w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) {
+            rc = fail(PN_ERR_DEVICE, "bf16 bounds failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        rc = PN_OK;
+    } while (0);
+    if (d_q) (void)hipFree(d_q);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

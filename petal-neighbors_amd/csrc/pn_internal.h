@@ -41,6 +41,7 @@ struct CandBuf {
     size_t nq_pad;   // queries padded to a multiple of kTileQ
     int nseg;
     int cap;         // slots per (segment, query); multiple of 64
+    int idx_stride = 1;  // 2: keys and idx interleaved as (key, row) pairs, idx = keys + 1 (bf16 filter)
 };
 
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
@@ -78,10 +79,13 @@ hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).
+// qn / qbad (nullable, [nq]): the thresholds bound |q-p|^2 - |q|^2 (bf16 filter), qn[q] <= |q|^2 is added back;
+// qbad[q] != 0 flags the query outright
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, uint32_t *flags,
-                                    uint32_t *n_flagged, uint64_t *n_cand, hipStream_t s);
+                                    uint32_t *n_flagged, uint64_t *n_cand, const double *qn, const uint32_t *qbad,
+                                    hipStream_t s);
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s);
@@ -135,5 +139,25 @@ hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, s
                                    uint32_t *kept, uint32_t *nkept, uint32_t *overflow, hipStream_t s);
 hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
                                 size_t kept_stride, uint64_t index_base, uint64_t *out, hipStream_t s);
+
+// ---- bf16_filter.hip: first-tier filter (bf16 MFMA lower bound of |q-p|^2 - |q|^2), D <= 128
+bool bf16_supported(int dim);
+int bf16_ks_for(int dim);
+size_t bf16_image_bytes(size_t n, int dim);        // corpus tile images
+size_t bf16_query_bytes(size_t nq_pad, int dim);   // packed query rows
+int bf16_cap_for(int kp);                          // slots per (segment, query): 64 / 128 / 256
+int bf16_query_tile();                             // queries per workgroup (256)
+hipError_t launch_bf16_pack_corpus(const float *P, size_t n, int dim, size_t ld, void *img, uint32_t *bad,
+                                   hipStream_t s);
+hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, int dim, size_t ld, void *B, double *qn,
+                                    uint32_t *qbad, hipStream_t s);
+// split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
+// tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
+int bf16_segments(size_t q_tiles, int n_wg, int split);
+hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
+                              int split, int scout_max, hipStream_t s);
+// diagnostic: out[q][row] = L'(q, row), q < nq, row < n_rows
+hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
+                             hipStream_t s);
 
 }  // namespace pn

@@ -208,9 +208,10 @@ __device__ __forceinline__ float exact_distance_f32(const float *__restrict__ q,
 __global__ __launch_bounds__(64) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
-    size_t ldq, int dim, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
+    size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
     float *__restrict__ dist_out, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
-    unsigned long long *__restrict__ n_cand) {
+    unsigned long long *__restrict__ n_cand, const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
+    int idx_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t kth_key;
     const int lane = threadIdx.x;
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         const uint32_t c = ccnt[(size_t)s * nq_pad + q];
         const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
         for (uint32_t e = lane; e < c; e += 64) {
-            const uint32_t ix = cidx[base + e];
+            const uint32_t ix = cidx[(base + e) * (size_t)idx_stride];
             sidx[n + e] = ix;
-            skey[n + e] = sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim));
+            // a padding row (the bf16 filter may list one while a threshold is still +inf) sorts behind everything
+            skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
         }
         n += c;
     }
@@ -263,9 +265,14 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
             const double mid = 0.5 * (dk + dn);
             const double rhs = mid * mid * (1.0 + 4.5e-16);
             const double u = 5.9604644775390625e-08;  // 2^-24
-            const double lb = (double)min_tau * (1.0 - (double)(dim + 4) * u) - 1e-37;
+            // bf16 filter: the thresholds are TAGGED bounds of d2 - |q|^2 (bf16_filter.hip): within 2^-19 relative
+            // of the bound itself; qn[q] <= |q|^2
+            const double d2_lb = qn ? ((double)min_tau - fabs((double)min_tau) * 1.9073486328125e-06) + qn[q]
+                                    : (double)min_tau;
+            const double lb = d2_lb * (1.0 - (double)(dim + 4) * u) - 1e-37;
             ok = (min_tau == min_tau) && (lb > rhs);
         }
+        if (qbad && qbad[q]) ok = false;
         flags[q] = ok ? 0u : 1u;
         if (!ok) atomicAdd(n_flagged, 1u);
         atomicAdd(n_cand, (unsigned long long)n_all);
@@ -275,14 +282,13 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, uint32_t *flags, uint32_t *n_flagged,
-                                    uint64_t *n_cand, hipStream_t s) {
-    (void)n;
+                                    uint64_t *n_cand, const double *qn, const uint32_t *qbad, hipStream_t s) {
     const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 8;
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
-                       ldq, dim, kout, index_base, idx_out, dist_out, flags, n_flagged,
-                       reinterpret_cast<unsigned long long *>(n_cand));
+                       ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, flags, n_flagged,
+                       reinterpret_cast<unsigned long long *>(n_cand), qn, qbad, cb.idx_stride);
     return hipGetLastError();
 }
 

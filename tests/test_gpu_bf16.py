@@ -1,0 +1,197 @@
+"""bf16 first tier (petal-neighbors_amd/csrc/bf16_filter.hip) on an MI355X.
+
+Two kinds of test:
+  * the INEQUALITY the tier's proof rests on -- L'(q,p) + qn <= |q-p|^2 with qn <= |q|^2 -- checked pair by
+    pair against f64, on benign and on hostile data, together with the measured accumulation error of the
+    matrix core against the allowance g = 2^-13 the proof makes;
+  * END-TO-END parity: results through the C ABI with the bf16 tier forced are bit-identical to the oracle,
+    whatever the tier could or could not prove (unproven queries go to the f32 tiers).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _bounds(pn, tree, qs, n_rows):
+    from petal_neighbors_amd import _lib
+    from petal_neighbors_amd.errors import check
+    qs = np.ascontiguousarray(qs, dtype=np.float32)
+    nq, d = qs.shape
+    n_rows = min(n_rows, tree.num_points())
+    out = np.empty((nq, n_rows), dtype=np.float32)
+    qn = np.empty(nq, dtype=np.float64)
+    check(_lib.lib().pn_bf16_bounds_f32(tree._h, qs.ctypes.data, nq, d, d, n_rows, out.ctypes.data, qn.ctypes.data))
+    return out, qn
+
+
+def _bf16_round(x):
+    """round-to-nearest-even bf16 of an f32 array (as f32), with the filter's 2^-60 flush"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    y = r.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+    return np.where(np.abs(x) < 2.0 ** -60, np.float32(0), y)
+
+
+CASES = {
+    "uniform": lambda n, d, s: uniform((n, d), s),
+    "centered": lambda n, d, s: uniform((n, d), s) - np.float32(0.5),
+    "offset1000": lambda n, d, s: uniform((n, d), s) + np.float32(1000.0),
+    "scaled1e6": lambda n, d, s: (uniform((n, d), s) - np.float32(0.5)) * np.float32(1e6),
+    "tiny1e-20": lambda n, d, s: (uniform((n, d), s) - np.float32(0.5)) * np.float32(1e-20),
+    "sparse": lambda n, d, s: np.where(uniform((n, d), s + 7) < 0.9, np.float32(0), uniform((n, d), s)).astype(np.float32),
+    "mixed_scales": lambda n, d, s: ((uniform((n, d), s) - np.float32(0.5))
+                                      * (np.float32(10.0) ** (np.arange(d, dtype=np.float32) % 9 - 4))).astype(np.float32),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("dim", [8, 33, 96, 128])
+def test_lower_bound_inequality(pn, name, dim):
+    n, nq = 4096, 96
+    pts = CASES[name](n, dim, 11)
+    qs = CASES[name](nq, dim, 12)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible
+    L, qn = _bounds(pn, tree, qs, 1024)
+    p64, q64 = pts[:1024].astype(np.float64), qs.astype(np.float64)
+    qq = (q64 * q64).sum(1)
+    assert np.all(qn <= qq) and np.all(qn >= qq * (1 - 1e-11))
+    d2 = ((q64[:, None, :] - p64[None, :, :]) ** 2).sum(2)
+    assert np.all(np.isfinite(L))
+    gap = d2 - (L.astype(np.float64) + qn[:, None])
+    assert gap.min() >= 0.0, f"{name}/D={dim}: bound exceeds the squared distance by {-gap.min()}"
+    # the bound is useful on benign data: slack small against the spread of the squared distances
+    if name in ("uniform", "centered"):
+        assert gap.max() < 0.05 * d2.mean() + 1e-3
+
+
+@pytest.mark.parametrize("dim", [16, 128])
+def test_accumulation_error_within_allowance(pn, dim):
+    """|MFMA result - exact sum of its bf16 terms| against g * (sum of magnitudes): the proof assumes ratio <= 1
+    with g = 2^-13; the measured ratio is reported so a regression in margin is visible."""
+    n, nq = 2048, 64
+    pts = (uniform((n, dim), 21) - np.float32(0.5)) * np.float32(3.0)
+    qs = (uniform((nq, dim), 22) - np.float32(0.5)) * np.float32(3.0)
+    tree = pn.BallTree.euclidean(pts)
+    L, qn = _bounds(pn, tree, qs, n)
+    ph, qh = _bf16_round(pts).astype(np.float64), _bf16_round(qs).astype(np.float64)
+    p64, q64 = pts.astype(np.float64), qs.astype(np.float64)
+    g = 2.0 ** -13
+    # lower / upper envelopes of the exact sum of the bf16 terms (the extra columns are rounded outward by at
+    # most 2^-7 relative each; the data columns are exact)
+    pn_ = (p64 * p64).sum(1)
+    dot = qh @ ph.T
+    ep, eq = np.sqrt(((p64 - ph) ** 2).sum(1)), np.sqrt(((q64 - qh) ** 2).sum(1))
+    nph, nqh, npp = np.sqrt((ph * ph).sum(1)), np.sqrt((qh * qh).sum(1)), np.sqrt(pn_)
+    slack = nqh[:, None] * (2 * ep + 2 * g * nph)[None, :] + eq[:, None] * (2 * npp)[None, :]
+    hi = pn_[None, :] - 2 * dot - slack                                  # every outward rounding at its least
+    lo = pn_[None, :] * (1 - g) * (1 - 2.0 ** -21) - 2 * dot - slack * (1 + 2 * g) * (1 + 2.0 ** -7) ** 2
+    mag = pn_[None, :] + 2 * np.abs(qh) @ np.abs(ph).T + slack * 1.02
+    over = (L.astype(np.float64) - hi) / (g * mag)   # > 0 only through accumulation error
+    under = (lo - L.astype(np.float64)) / (g * mag)
+    worst = max(over.max(), under.max())
+    print(f"D={dim}: accumulation error / allowance = {worst:.4f}")
+    assert worst < 0.25, f"matrix-core accumulation error uses {worst:.2f} of the allowance (expected < 0.25)"
+
+
+def _check(pn, oracle_mod, pts, qs, k, opts=None, expect_fallback=None):
+    from petal_neighbors_amd import _lib
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible
+    tree.set_engine("bf16")
+    for o, v in (opts or {}).items():
+        tree.set_option(o, v)
+    idx, dist = tree.query_batch(qs, k)
+    oidx, odist = oracle_mod.brute_knn(pts, qs, k)
+    assert dist.tobytes() == odist.tobytes(), "distances differ"
+    assert np.array_equal(idx, oidx), "indices differ"
+    st = tree.stats()
+    if expect_fallback is not None:
+        assert (st["fallback_queries"] > 0) == expect_fallback, st
+    return tree, st
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(5000, 128, 300, 10), (20000, 96, 700, 1), (9000, 64, 257, 25),
+                                          (4100, 8, 130, 3), (30000, 128, 64, 100), (6000, 33, 500, 7),
+                                          (4096, 17, 1, 5), (70000, 128, 1000, 10)])
+def test_bf16_engine_parity(pn, oracle_mod, n, dim, nq, k):
+    pts = uniform((n, dim), 100 + dim)
+    qs = uniform((nq, dim), 200 + dim)
+    _check(pn, oracle_mod, pts, qs, k)
+
+
+def test_bf16_engine_is_the_auto_default_and_proves_uniform_data(pn, oracle_mod):
+    pts = uniform((50000, 128), 5)
+    qs = uniform((2000, 128), 6)
+    tree = pn.BallTree.euclidean(pts)
+    idx, dist = tree.query_batch(qs, 10)  # engine auto
+    oidx, odist = oracle_mod.brute_knn(pts, qs, 10)
+    assert dist.tobytes() == odist.tobytes() and np.array_equal(idx, oidx)
+    st = tree.stats()
+    assert st["fallback_queries"] <= 20, st
+    assert 10 <= st["candidates"] / st["queries"] <= 2000, st
+
+
+def test_bf16_hostile_data_falls_back_and_stays_exact(pn, oracle_mod):
+    # large common offset: bf16 resolves nothing, every query must be handed to the f32 tiers
+    pts = uniform((8000, 64), 31) + np.float32(1000.0)
+    qs = uniform((200, 64), 32) + np.float32(1000.0)
+    _check(pn, oracle_mod, pts, qs, 5, expect_fallback=True)
+
+
+def test_bf16_ties_and_duplicates(pn, oracle_mod):
+    base = uniform((3000, 32), 41)
+    pts = np.concatenate([base, base[:1500], base[:700]]).astype(np.float32)  # exact duplicates -> distance ties
+    qs = np.concatenate([base[:64], uniform((64, 32), 42)]).astype(np.float32)
+    _check(pn, oracle_mod, pts, qs, 12)
+
+
+def test_bf16_clustered_order(pn, oracle_mod):
+    # corpus sorted by cluster: all neighbours of a query sit in one segment
+    rng = np.random.default_rng(3)
+    centers = rng.random((16, 48), dtype=np.float32) * 10
+    pts = np.concatenate([c + 0.05 * rng.standard_normal((1000, 48), dtype=np.float32) for c in centers]).astype(np.float32)
+    qs = (centers[rng.integers(0, 16, 300)] + 0.05 * rng.standard_normal((300, 48), dtype=np.float32)).astype(np.float32)
+    _check(pn, oracle_mod, pts, qs, 10)
+
+
+def test_bf16_small_slots_force_fallback(pn, oracle_mod):
+    from petal_neighbors_amd import _lib
+    pts = uniform((20000, 128), 51)
+    qs = uniform((256, 128), 52)
+    # k' = k and a single segment: the k-th bound can never clear the k-th distance
+    _check(pn, oracle_mod, pts, qs, 10, opts={_lib.PN_OPT_FILTER_SLOTS: 10, _lib.PN_OPT_SEGMENTS: 1},
+           expect_fallback=True)
+
+
+def test_bf16_nonfinite_query_and_large_k(pn, oracle_mod):
+    pts = uniform((6000, 40), 61)
+    qs = uniform((70, 40), 62)
+    qs[3, 5] = np.nan
+    qs[9, 0] = np.inf
+    qs[11, :] = 1e25
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine("bf16")
+    for k in (4, 150):
+        idx, dist = tree.query_batch(qs, k)
+        oidx, odist = oracle_mod.brute_knn(pts, qs, k)
+        na, nb = np.isnan(dist), np.isnan(odist)
+        assert np.array_equal(na, nb) and dist[~na].tobytes() == odist[~nb].tobytes()
+        ok = ~np.isnan(odist).any(axis=1) & ~np.isinf(odist).any(axis=1)
+        assert np.array_equal(idx[ok], oidx[ok])
+
+
+def test_bf16_ineligible_index(pn):
+    pts = uniform((5000, 16), 71)
+    pts[17, 3] = np.inf
+    tree = pn.BallTree.euclidean(pts)
+    assert not tree.bf16_eligible
+    with pytest.raises(Exception):
+        tree.set_engine("bf16")
+    wide = pn.BallTree.euclidean(uniform((5000, 200), 72))
+    assert not wide.bf16_eligible
