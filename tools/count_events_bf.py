@@ -20,6 +20,6 @@ t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 units = 40 * 4 * 2 * 31250
 print("slow calls", out[0], "(%.3f of wave-block-qb units)" % (out[0] / units), "appends", out[1], "per query %.1f" % (out[1] / 10240),
       "lanes with survivors per call %.2f" % (out[4] / max(out[0], 1)), "compactions", out[2],
-      "ticks per slow call %.0f" % (out[3] / max(out[0], 1)), "= scan %.0f + append %.0f + compaction %.0f" %
-      (out[5] / max(out[0], 1), out[6] / max(out[0], 1), out[7] / max(out[0], 1)),
-      "slow ticks per wave %.3gM" % (out[3] / 2048 / 1e6))
+      "per slow call: %.0f ns = count %.0f + append %.0f + compaction check %.0f;" % tuple(10 * out[i] / max(out[0], 1) for i in (3, 5, 6, 7)),
+      "per compaction %.2f us; per wave: slow path %.2f ms of which compactions %.2f ms" % (10e-3 * out[7] / max(out[2], 1), 10e-6 * out[3] / 2048, 10e-6 * out[7] / 2048),
+      "")
