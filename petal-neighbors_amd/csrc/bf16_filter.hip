@@ -282,7 +282,10 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
 // cnt is the fill count of the lane's query (identical in lanes j and j+32, which hold different rows).
 // ns counts the vector-memory instructions this wave has issued since its last LDS-DMA (wave-uniform): the
 // wait in front of the tile barrier must cover the DMA but not these younger stores (see bf_wait_dma).
-template <int M>
+// RAD (radius queries): the threshold is the query's fixed radius bound and every row below it must be kept, so
+// a buffer that would need compacting is marked overflowed instead (count > capacity; the host re-runs the call
+// on the exact engine) and its threshold drops to -inf so that nothing more is stored.
+template <int M, bool RAD>
 __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
                                         int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk, uint32_t &ns) {
 #ifdef PN_DIAG_BF_NOSLOW  // timing-only build: results are wrong
@@ -344,6 +347,13 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
 #ifdef PN_DIAG_BF_COUNT
     const unsigned long long t2_ = bf_stamp();
 #endif
+    if (RAD) {
+        if (cnt > CAP - 32) {  // would need compacting: overflow, and nothing more is stored
+            cnt = CAP + 1;
+            tau = __uint_as_float(0xFF800000u);
+        }
+        return;
+    }
     unsigned long long need = __ballot(h == 0 && cnt > CAP - 32);
     if (need) {
         // the entries were stored by both halves of the wave: they must have left before they are read back
@@ -402,14 +412,15 @@ __device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
 }
 
 // cand: [nseg][nq_pad][64*M] (key, row) pairs; ccnt/ctau: [nseg][nq_pad], pre-initialised to 0 / sortable(+inf)
-template <int KS, int M>
+template <int KS, int M, bool RAD>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
                                                              uint32_t kp, uint2 *__restrict__ cand,
                                                              uint32_t *__restrict__ ccnt,
                                                              uint32_t *__restrict__ ctau, size_t nq_pad,
                                                              uint32_t split, uint32_t seg_per_part,
-                                                             uint32_t scout_max) {
+                                                             uint32_t scout_max,
+                                                             const uint32_t *__restrict__ tau_init) {
     constexpr int C = 2 * KS, CP = C + 1;
     constexpr uint32_t CAP = 64u * M;
     constexpr int TB = kBP * CP * 16;  // bytes per tile image
@@ -492,6 +503,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         uint32_t t_scout = run_len / 16u < 64u ? run_len / 16u : 64u;
         if (t_scout > scout_max) t_scout = scout_max;  // host: keeps the scouted rows' share of true neighbours tiny
         if (t_scout < 4u) t_scout = 0;
+        if (tau_init) {  // thresholds given by the caller (radius queries): no scouting
+            t_scout = 0;
+            tau0 = s2f(tau_init[q0 + jq]);
+            tau1 = s2f(tau_init[q0 + 32 + jq]);
+        }
 #endif
         if (t_scout) {
             const float inf = __uint_as_float(0x7F800000u);
@@ -582,16 +598,16 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             ns = 0;
             if (__any(p0 < tau0 || p1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP;
-                if (__any(p0 < tau0)) bf_slow<M>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-                if (__any(p1 < tau1)) bf_slow<M>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
             }
             float m0, m1;
             bf_chain<KS, true>(arow0, pre0, b0, b1, a00, a01, a10, a11, m0, m1);
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
-                if (__any(m0 < tau0)) bf_slow<M>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-                if (__any(m1 < tau1)) bf_slow<M>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
             }
             bf_chain<KS, true>(arow1, pre1, b0, b1, a10, a11, a00, a01, p0, p1);
             // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
@@ -617,16 +633,16 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m1 = fminf(m1, a11[i]);
             }
             uint32_t row0 = (rt1 - 1) * kBP;
-            if (__any(p0 < tau0)) bf_slow<M>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-            if (__any(p1 < tau1)) bf_slow<M>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+            if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
             row0 += 32;
-            if (__any(m0 < tau0)) bf_slow<M>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-            if (__any(m1 < tau1)) bf_slow<M>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
         }
         // ---- end of run: at most kp candidates per query stay; publish count and threshold
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned long long need = __ballot(h == 0 && cnt0 > kp);
+            unsigned long long need = RAD ? 0ull : __ballot(h == 0 && cnt0 > kp);
             while (need) {
                 const int j = __builtin_ctzll(need);
                 need &= need - 1;
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
                 if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
             }
-            need = __ballot(h == 0 && cnt1 > kp);
+            need = RAD ? 0ull : __ballot(h == 0 && cnt1 > kp);
             while (need) {
                 const int j = __builtin_ctzll(need);
                 need &= need - 1;
@@ -702,12 +718,12 @@ hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, in
     return hipGetLastError();
 }
 
-template <int KS, int M>
+template <int KS, int M, bool RAD>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                hipStream_t s) {
+                                const uint32_t *tau_init, hipStream_t s) {
     const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
-    auto kern = bf16_filter_kernel<KS, M>;
+    auto kern = bf16_filter_kernel<KS, M, RAD>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -717,18 +733,25 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,
                        static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,
-                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max);
+                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init);
     return hipGetLastError();
 }
 
 template <int KS>
 static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                hipStream_t s) {
+                                const uint32_t *tau_init, bool radius, hipStream_t s) {
+    if (radius)
+        return cb.cap == 128 && tau_init ? launch_bf16_t<KS, 2, true>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp,
+                                                                      scout_max, tau_init, s)
+                                         : hipErrorInvalidValue;
     switch (cb.cap) {
-        case 64: return launch_bf16_t<KS, 1>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
-        case 128: return launch_bf16_t<KS, 2>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
-        case 256: return launch_bf16_t<KS, 4>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, s);
+        case 64:
+            return launch_bf16_t<KS, 1, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
+        case 128:
+            return launch_bf16_t<KS, 2, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
+        case 256:
+            return launch_bf16_t<KS, 4, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -741,7 +764,7 @@ int bf16_segments(size_t q_tiles, int n_wg, int split) {
 }
 
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
-                              int split, int scout_max, hipStream_t s) {
+                              int split, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s) {
     if (!bf16_supported(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
         cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0)
         return hipErrorInvalidValue;
@@ -752,16 +775,36 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     if (cb.nseg < (int)(spp * split)) return hipErrorInvalidValue;
     const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
     switch (bf16_ks_for(dim)) {
-        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
-        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, s);
+        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+// radius queries: per-query threshold of the filter.  A row can only be within the radius when its exact squared
+// distance is below tau_r (computed by the host with the rounding allowances of select.hip's proof), hence when
+// L' < tau_r - |q|^2_down.  out[q] = sortable key of that bound rounded up to f32 and one step beyond (strict <).
+__global__ void bf16_radius_tau_kernel(const double *__restrict__ qn, size_t nq_pad, double tau_r,
+                                       uint32_t *__restrict__ out) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    const double t = tau_r - qn[q];
+    float f = (float)t;
+    if ((double)f < t) f = nextafterf(f, __uint_as_float(0x7F800000u));
+    f = nextafterf(f, __uint_as_float(0x7F800000u));
+    out[q] = f2s(f);
+}
+
+hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_radius_tau_kernel, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, s, qn, nq_pad, tau_r,
+                       out);
+    return hipGetLastError();
 }
 
 // debug / test entry: L'(q, p) for every pair of a small problem, straight from the MFMA (one wave per

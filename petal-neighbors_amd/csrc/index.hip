@@ -119,7 +119,7 @@ struct pn_index {
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
     mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
-    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc;  // bf16 tier
+    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed;  // bf16 tier
     mutable pn_stats stats{};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
@@ -325,7 +325,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
                       &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
                       &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo,
                       &ix->w_bq, &ix->w_qn, &ix->w_qbad, &ix->w_bflags, &ix->w_gq, &ix->w_gidx, &ix->w_gdist,
-                      &ix->w_gsel, &ix->w_bmisc};
+                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
@@ -763,7 +763,7 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
     HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, plan.split,
-                              plan.scout_max, s));
+                              plan.scout_max, nullptr, false, s));
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_bflags.p, d_nflag,
@@ -957,43 +957,9 @@ template <> struct RadOps<double> {
 // query_radius through the MFMA filter (f32, D <= 128, finite positive r).  *done = false means the
 // caller must run the exact two-pass engine instead (a survivor list overflowed, or a query norm is not
 // finite): correctness never depends on this path being taken.
-static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
-                       uint64_t **idx_out, bool *done, hipStream_t s) {
-    *done = false;
-    const uint32_t cap = 32;
-    const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
-    size_t n_wg = (size_t)ix->n_cu * 2;
-    size_t cap_wg = q_tiles * 32;
-    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
-    if (by_work < cap_wg) cap_wg = by_work;
-    if (cap_wg < 1) cap_wg = 1;
-    if (n_wg > cap_wg) n_wg = cap_wg;
-    const int nseg = mfma_v2_max_segments(q_tiles, (int)n_wg);
-    const size_t cells = (size_t)nseg * nq_pad;
-    const size_t kept_stride = (size_t)nseg * cap;
-    // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24), rounded up; the kernel tests L < succ(tau_r)
-    const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
-    float tf = (float)t;
-    if ((double)tf < t) tf = nextafterf(tf, INFINITY);
-    if (!(tf < INFINITY)) return PN_OK;  // r^2 overflows f32: let the exact engine decide
-    const float tau_excl = nextafterf(tf, INFINITY);
-
-    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
-    PNCHK(ix->w_misc.ensure(64));
-    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_idx.ensure(cells * cap * sizeof(uint32_t)));
-    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));  // kept rows per query
-    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));           // kept counts
-    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] non-finite query norms
-    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
-    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
-                                d_misc + 1, s));
-    HIPCHK(launch_mfma_radius_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ix->w_qnorm.p,
-                                  nq_pad, tau_excl, cap, (uint32_t *)ix->w_cnt.p, (uint32_t *)ix->w_idx.p, (int)n_wg, s));
-    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p, nq_pad, nseg, cap,
-                                   (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, s));
+// common tail of the filtered radius paths: kept rows per query (w_keys, ascending) -> CSR on the host
+static int radius_finish(const pn_index *ix, size_t nq, size_t kept_stride, uint32_t *d_misc, uint64_t *offsets,
+                         uint64_t **idx_out, bool *done, hipStream_t s) {
     uint32_t h_misc[2] = {0, 0};
     std::vector<uint32_t> h_n(nq);
     HIPCHK(hipMemcpyAsync(h_misc, d_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
@@ -1035,6 +1001,92 @@ static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     return PN_OK;
 }
 
+// first tier for radius queries: the bf16 filter against each query's fixed bound, exact check of the survivors
+static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+                       uint64_t **idx_out, bool *done, hipStream_t s) {
+    *done = false;
+    const int cap = 128;  // up to 96 rows within the radius per (segment, query) before the call overflows
+    const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
+    size_t n_wg = (size_t)ix->n_cu * 2;
+    size_t cap_wg = q_tiles * 32;
+    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    if (by_work < cap_wg) cap_wg = by_work;
+    if (cap_wg < 1) cap_wg = 1;
+    if (n_wg > cap_wg) n_wg = cap_wg;
+    const int nseg = bf16_segments(q_tiles, (int)n_wg, 1);
+    const size_t cells = (size_t)nseg * nq_pad;
+    const size_t kept_stride = (size_t)nseg * cap;
+    // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24): every row whose reference distance is < r has a squared distance
+    // below it (same allowances as the k-NN proof)
+    const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
+    if (!(t < 1e37)) return PN_OK;  // let the exact engine decide
+    PNCHK(ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ix->w_qn.ensure(nq_pad * sizeof(double)));
+    PNCHK(ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_misc.ensure(64));
+    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_idx.ensure(cells * cap * 2 * sizeof(uint32_t)));      // (key, row) pairs
+    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));    // kept rows per query
+    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));             // kept counts
+    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
+    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+                                    (uint32_t *)ix->w_qbad.p, s));
+    PNCHK(ix->w_gsel.ensure(nq * sizeof(uint32_t)));
+    HIPCHK(launch_compact_flags((const uint32_t *)ix->w_qbad.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_misc + 1, s));
+    HIPCHK(launch_bf16_radius_tau((const double *)ix->w_qn.p, nq_pad, t, (uint32_t *)ix->w_seed.p, s));
+    CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
+    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
+                              (const uint32_t *)ix->w_seed.p, true, s));
+    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p + 1, nq_pad, nseg, cap,
+                                   (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
+                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2, s));
+    return radius_finish(ix, nq, kept_stride, d_misc, offsets, idx_out, done, s);
+}
+
+static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+                       uint64_t **idx_out, bool *done, hipStream_t s) {
+    *done = false;
+    const uint32_t cap = 32;
+    const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
+    size_t n_wg = (size_t)ix->n_cu * 2;
+    size_t cap_wg = q_tiles * 32;
+    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    if (by_work < cap_wg) cap_wg = by_work;
+    if (cap_wg < 1) cap_wg = 1;
+    if (n_wg > cap_wg) n_wg = cap_wg;
+    const int nseg = mfma_v2_max_segments(q_tiles, (int)n_wg);
+    const size_t cells = (size_t)nseg * nq_pad;
+    const size_t kept_stride = (size_t)nseg * cap;
+    // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24), rounded up; the kernel tests L < succ(tau_r)
+    const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
+    float tf = (float)t;
+    if ((double)tf < t) tf = nextafterf(tf, INFINITY);
+    if (!(tf < INFINITY)) return PN_OK;  // r^2 overflows f32: let the exact engine decide
+    const float tau_excl = nextafterf(tf, INFINITY);
+
+    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
+    PNCHK(ix->w_misc.ensure(64));
+    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ix->w_idx.ensure(cells * cap * sizeof(uint32_t)));
+    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));  // kept rows per query
+    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));           // kept counts
+    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] non-finite query norms
+    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
+                                d_misc + 1, s));
+    HIPCHK(launch_mfma_radius_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ix->w_qnorm.p,
+                                  nq_pad, tau_excl, cap, (uint32_t *)ix->w_cnt.p, (uint32_t *)ix->w_idx.p, (int)n_wg, s));
+    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p, nq_pad, nseg, cap,
+                                   (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
+                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 1, s));
+    return radius_finish(ix, nq, kept_stride, d_misc, offsets, idx_out, done, s);
+}
+
 template <typename T>
 static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, T radius,
                             uint64_t *offsets, uint64_t **idx_out) {
@@ -1051,7 +1103,7 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
     std::lock_guard<std::mutex> lk(ix->mu);
     hipStream_t s = ix->stream;
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
-    const size_t nq_pad = round_up(nq, (size_t)128);
+    const size_t nq_pad = round_up(nq, (size_t)256);
     T *d_q = nullptr;
     uint32_t *d_counts = nullptr;
     uint64_t *d_offs = nullptr, *d_fill = nullptr;
@@ -1069,6 +1121,12 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
         }
         if constexpr (sizeof(T) == 4) {
             const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
+            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
+                (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
+                bool done = false;
+                rc = radius_bf16(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
+                if (rc != PN_OK || done) break;
+            }
             if (ix->mfma_ok && ix->ld <= 128 && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && finite_pos &&
                 (ix->engine == PN_ENGINE_MFMA || (ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;

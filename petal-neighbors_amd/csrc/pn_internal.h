@@ -134,9 +134,10 @@ hipError_t launch_mfma_radius_f32(const float *P, const float *pnorm, size_t n, 
                                   uint32_t *ridx, int n_wg, hipStream_t s);
 // per query: exact distance of every listed row, keep dist < r, order by row; kept[q][*], nkept[q]; *overflow += 1
 // when some list of the query exceeded `cap`
+// ridx_stride: element stride of the row lists (2 when they are the rows of (key, row) pairs)
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
-                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, hipStream_t s);
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride, hipStream_t s);
 hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
                                 size_t kept_stride, uint64_t index_base, uint64_t *out, hipStream_t s);
 
@@ -154,8 +155,11 @@ hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, in
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);
+// tau_init (nullable, [nq_pad] sortable keys): starting thresholds instead of the scout pass.  radius = true:
+// fixed thresholds (tau_init required, cb.cap == 128), buffers overflow (count = cap + 1) instead of compacting
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
-                              int split, int scout_max, hipStream_t s);
+                              int split, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s);
+hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);
 // diagnostic: out[q][row] = L'(q, row), q < nq, row < n_rows
 hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
                              hipStream_t s);

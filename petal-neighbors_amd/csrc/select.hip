@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
                                                           uint32_t cap, const float *__restrict__ P, size_t ldp,
                                                           const float *__restrict__ Q, int dim, float r,
                                                           uint32_t *__restrict__ kept, uint32_t *__restrict__ nkept,
-                                                          uint32_t *__restrict__ overflow) {
+                                                          uint32_t *__restrict__ overflow, int ridx_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *srow = reinterpret_cast<uint32_t *>(smem);  // rows that pass the exact test
     __shared__ uint32_t n_pass;
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
     bool over = false;
     for (int s = 0; s < nseg; ++s) {
         uint32_t c = rcnt[(size_t)s * nq_pad + q];
-        if (c > cap) { over = true; c = cap; }
+        if (c > cap) { over = true; c = 0; }  // the call is re-run exactly; an overflowed list may hold unwritten slots
         const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
         for (uint32_t e = lane; e < c; e += 64) {
-            const uint32_t row = ridx[base + e];
+            const uint32_t row = ridx[(base + e) * (size_t)ridx_stride];
             const float d = exact_distance_f32(qrow, P + (size_t)row * ldp, dim);
             if (d < r) srow[atomicAdd(&n_pass, 1u)] = row;  // strict '<' (src/ball_tree.rs:277); NaN never matches
         }
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
 
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
-                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, hipStream_t s) {
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride, hipStream_t s) {
     const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q,
-                       dim, r, kept, nkept, overflow);
+                       dim, r, kept, nkept, overflow, ridx_stride);
     return hipGetLastError();
 }
 

@@ -354,9 +354,9 @@ def test_query_radius_vs_oracle(pn, oracle_mod, dtype):
     assert list(t.query_radius(np.array([3.0], dtype=dtype), 1.0)) == [2]
 
 
-@pytest.mark.parametrize("engine", ["mfma", "auto", "exact"])
+@pytest.mark.parametrize("engine", ["bf16", "mfma", "auto", "exact"])
 def test_query_radius_mfma_filter(pn, oracle_mod, engine):
-    """query_radius through the MFMA filter: sparse results stay on it, dense results overflow the
+    """query_radius through the bf16 / f32 MFMA filters: sparse results stay on them, dense results overflow the
     survivor lists and are re-run exactly; boundary radii (r == an exact distance) keep the strict '<'."""
     for n, dim in ((20000, 128), (9000, 96), (6000, 16), (5000, 3)):
         pts = uniform((n, dim), 51 + n, np.float32)
