@@ -1,33 +1,29 @@
-// mfma_filter_v2.hip -- the dominant kernel, second structure (k' <= 32).
+// mfma_filter_v2.hip -- second tier of the k-NN path (and the radius filter of the f32 tier): proven lower
+// bounds of |q-p|^2 on the f32 matrix cores, persistent-partition structures.
 //
-// Same mathematics as mfma_filter.hip (read its header first: L(q,p) is a proven
-// lower bound of |q-p|^2 computed as one (D+2)-step fma chain on
-// v_mfma_f32_32x32x2_f32, query on the lane, 16 rows in registers).  What changes
-// is how the chip is kept busy; every item below was measured on the first
-// structure (profiles/r01_*):
+// Same mathematics as mfma_filter.hip (read its header first: L(q,p) is a proven lower bound of |q-p|^2
+// computed as one (D+2)-step fma chain on v_mfma_f32_32x32x2_f32, query on the lane, 16 rows in registers).
+// What this file changes is how the chip is kept busy; every item below was measured (profiles/r01_*):
 //
-//  * BALANCED PERSISTENT PARTITION.  The work is the list of (query tile, 64-row
-//    tile) units in query-major order; workgroup w of W (= one per CU) owns the
-//    contiguous slice [w*U/W, (w+1)*U/W).  Every workgroup gets the same number
-//    of MFMAs (+-1 tile) for any Q and N -- the static (query tile x segment)
-//    grid left 6-7 % of the workgroup slots empty at Q = 10^4.  A slice crosses
-//    at most a few query-tile boundaries; at each it flushes its candidates and
-//    reloads the B operand.  "Segment" of a query tile = ordinal of the
-//    workgroup among those that touch it (<= ceil(W/QT)+1 of them).
-//  * ONE WAVE PER SIMD, SOFTWARE PIPELINED.  Two accumulator sets: the 130-MFMA
-//    chain of tile t runs while the VALU reduces tile t-1 (min over its 32
-//    bounds, compare with the lane's threshold), so the matrix pipe only drains
-//    at the one barrier per tile.  (Two workgroups per CU hid far less than
-//    expected: 14 % of the pipe stayed idle behind barrier skew.)
-//  * CANDIDATES IN LDS.  Per query 64 (key,row) slots in LDS instead of HBM: an
-//    append is an LDS atomic + two ds_writes -- no global stores whose drain
-//    (s_waitcnt vmcnt(0)) stalled the next chain, no store/load mix that makes
-//    hipcc's wait-count pass insert vmcnt(0) in the chain.  With 64 slots the
-//    two 32-row blocks of a tile are appended separately, each followed by the
-//    radix-select compaction when more than 32 slots are in use, so a block
-//    (<= 32 survivors per query) always fits.
+//  * BALANCED PERSISTENT PARTITION.  The work is the list of (query tile, 64-row tile) units in query-major
+//    order; workgroup w of W owns the contiguous slice [w*U/W, (w+1)*U/W).  Every workgroup gets the same number
+//    of MFMAs (+-1 tile) for any Q and N -- the static (query tile x segment) grid of mfma_filter.hip left 6-7 %
+//    of the workgroup slots empty at Q = 10^4.  A slice crosses at most a few query-tile boundaries; at each it
+//    flushes its candidates and reloads the B operand.  "Segment" of a query tile = ordinal of the workgroup
+//    among those that touch it (<= ceil(W/QT)+1 of them).
+//  * SOFTWARE PIPELINE.  Two accumulator sets: the 65-MFMA chain of one 32-row block runs while the VALU
+//    reduces the previous block (minimum of its 16 bounds, compare with the lane's threshold), so the matrix
+//    pipe only drains at the one barrier per tile.
+//  * TILES BY LDS-DMA (global_load_lds, 16 B per lane) into an XOR-swizzled image (D = 64, 128); register
+//    staging for the other row lengths.
+//  * CANDIDATE BUFFERS: template GC.  GC = false ("structure 2"): 64 (key,row) slots per query in LDS, one
+//    workgroup per CU.  GC = true ("structure 3", the default): buffers in a per-workgroup HBM slab, LDS holds
+//    only the tiles, TWO workgroups per CU -- a second wave per SIMD runs while the first sits in its rare path,
+//    at a barrier or at the head of a chain (C2: 22.1 ms vs 24.0 ms), and k' up to 224 (64*M slots, M = 1, 2, 4).
+//  * D > 128: mfma_filter_wide_kernel processes rows in 128-coordinate slabs.
+//  * mfma_radius_kernel: the same chain against one fixed threshold, survivor lists instead of top-k' buffers.
 //
-// LDS (D = 128): 2 x 33 KB tiles + 64 KB candidates + 1.5 KB = 132 KB of 160 KB.
+// LDS (D = 128): 2 x 32 KB tiles + 0.5 KB norms (+ 64 KB candidates when GC = false).
 #include "pn_internal.h"
 #include "topk_buffer.h"
 
