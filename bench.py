@@ -231,6 +231,7 @@ def main():
                                                   / (peak * world), 4)},
             "fallback_queries": int(st["fallback_queries"]),
             "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
+            "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, dim, k)

@@ -97,7 +97,9 @@ typedef struct pn_stats {
     double hot_ms;             /* their summed hipEvent duration (PN_OPT_PROFILE=1) */
     double last_call_ms;       /* hipEvent duration of the whole last profiled *_device call */
     uint64_t radius_results;
-    uint64_t reserved[4];
+    uint64_t evaluations;      /* candidates whose exact distance was actually computed (the others were proven
+                                  farther than the k-th from their filter bound alone) */
+    uint64_t reserved[3];
 } pn_stats;
 
 const char *pn_last_error(void);

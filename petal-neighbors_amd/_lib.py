@@ -27,7 +27,8 @@ class PnInfo(C.Structure):
 class PnStats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("fallback_queries", C.c_uint64), ("candidates", C.c_uint64),
                 ("hot_launches", C.c_uint64), ("hot_ms", C.c_double), ("last_call_ms", C.c_double),
-                ("radius_results", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("radius_results", C.c_uint64), ("evaluations", C.c_uint64),
+                ("reserved", C.c_uint64 * 3)]
 
 
 _sz, _ssz, _i, _vp, _u64 = C.c_size_t, C.c_ssize_t, C.c_int, C.c_void_p, C.c_uint64

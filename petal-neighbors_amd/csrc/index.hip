@@ -119,7 +119,7 @@ struct pn_index {
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
     mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
-    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed;  // bf16 tier
+    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed, w_qstat;  // bf16 tier
     mutable pn_stats stats{};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
@@ -325,7 +325,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
                       &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
                       &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo,
                       &ix->w_bq, &ix->w_qn, &ix->w_qbad, &ix->w_bflags, &ix->w_gq, &ix->w_gidx, &ix->w_gdist,
-                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed};
+                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed, &ix->w_qstat};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
@@ -683,6 +683,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
     PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
     PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
     CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_idx.p, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, plan.nseg, cap};
     if (v2) {  // not every (segment, query tile) cell is written by the persistent partition
         HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -704,9 +705,9 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_flags.p, d_nflag,
-                                    d_ncand, nullptr, nullptr, s));
-    struct { uint32_t nflag, qnonfinite; uint64_t ncand; } h{};
-    HIPCHK(hipMemcpyAsync(&h, ix->w_misc.p, 16, hipMemcpyDeviceToHost, s));
+                                    d_ncand, nullptr, nullptr, (uint32_t *)ix->w_qstat.p, s));
+    struct { uint32_t nflag, qnonfinite; uint64_t ncand; uint64_t pad[2]; uint64_t neval; } h{};
+    HIPCHK(hipMemcpyAsync(&h, ix->w_misc.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (prof) {
         float ms = 0;
@@ -715,6 +716,7 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
         ix->stats.hot_launches += 1;
     }
     ix->stats.candidates += h.ncand;
+    ix->stats.evaluations += h.neval;
     if (h.nflag) {
         // re-run the unproven queries on the exact engine
         const size_t nf = h.nflag;
@@ -750,6 +752,7 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
     PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
     PNCHK(ix->w_bflags.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ix->w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
     PNCHK(ix->w_bmisc.ensure(64));
     uint32_t *d_nflag = (uint32_t *)ix->w_bmisc.p;
     uint64_t *d_ncand = (uint64_t *)((char *)ix->w_bmisc.p + 8);
@@ -767,9 +770,10 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_bflags.p, d_nflag,
-                                    d_ncand, (const double *)ix->w_qn.p, (const uint32_t *)ix->w_qbad.p, s));
-    struct { uint32_t nflag, pad; uint64_t ncand; } h{};
-    HIPCHK(hipMemcpyAsync(&h, ix->w_bmisc.p, 16, hipMemcpyDeviceToHost, s));
+                                    d_ncand, (const double *)ix->w_qn.p, (const uint32_t *)ix->w_qbad.p,
+                                    (uint32_t *)ix->w_qstat.p, s));
+    struct { uint32_t nflag, pad; uint64_t ncand; uint64_t pad2[2]; uint64_t neval; } h{};
+    HIPCHK(hipMemcpyAsync(&h, ix->w_bmisc.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (prof) {
         float ms = 0;
@@ -778,6 +782,7 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
         ix->stats.hot_launches += 1;
     }
     ix->stats.candidates += h.ncand;
+    ix->stats.evaluations += h.neval;
     if (h.nflag) {
         // second tier for the unproven queries: the f32 MFMA filter (which has its own exact fallback)
         const size_t nf = h.nflag;

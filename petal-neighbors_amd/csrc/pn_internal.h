@@ -85,7 +85,7 @@ hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, uint32_t *flags,
                                     uint32_t *n_flagged, uint64_t *n_cand, const double *qn, const uint32_t *qbad,
-                                    hipStream_t s);
+                                    uint32_t *qstat /* scratch [2 * nq] for the statistics, nullable */, hipStream_t s);
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s);

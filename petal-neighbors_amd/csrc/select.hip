@@ -205,40 +205,177 @@ __device__ __forceinline__ float exact_distance_f32(const float *__restrict__ q,
     return sqrtf(s);
 }
 
+// The same fold with the row PREFETCHED: 16 independent 16-byte loads are issued before the first of them is
+// consumed (64 coordinates per round), and the query is read from LDS.  The plain loop above waits for memory once
+// per four coordinates; with a handful of lanes active per wave that latency, not arithmetic or bandwidth, was the
+// whole cost of the re-rank kernel.  len must be a multiple of 4 (device rows are zero padded to a multiple of 8:
+// the padding adds (0-0)*(0-0) = +0, which leaves every partial sum unchanged).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float exact_distance_prefetched_f32(const float *qs, const float *__restrict__ p, int len) {
+#pragma clang fp contract(off)
+    float s = 0.0f;
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        f32x4_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (k0 + 4 * i < len) v[i] = *reinterpret_cast<const f32x4_t *>(p + k0 + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (k0 + 4 * i < len) {
+                const f32x4_t a = *reinterpret_cast<const f32x4_t *>(qs + k0 + 4 * i);
+                float d;
+                d = a.x - v[i].x; s = s + d * d;
+                d = a.y - v[i].y; s = s + d * d;
+                d = a.z - v[i].z; s = s + d * d;
+                d = a.w - v[i].w; s = s + d * d;
+            }
+        }
+    }
+    return sqrtf(s);
+}
+
+// k-th smallest (1-based) of n LDS words, one wave, array left untouched: radix select, one ballot per 64 words
+// per bit.  Requires 1 <= k <= n.
+__device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane) {
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        uint32_t c = 0;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            c += (uint32_t)__popcll(__ballot(e < n && a[e] < cand));
+        }
+        if (c < k) T = cand;
+    }
+    return T;
+}
+
 __global__ __launch_bounds__(64) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
     size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
     float *__restrict__ dist_out, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
-    unsigned long long *__restrict__ n_cand, const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
-    int idx_stride) {
+    const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
+    int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ qstat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t kth_key;
+    __shared__ uint32_t seg_off[65], seg_cnt[64];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
-    int total_cap = 0;
+    // Gather phase with few dependent memory round trips (a wave per query spends its time waiting, not computing):
+    // the lanes read the cells' counts and thresholds side by side, a wave scan turns the counts into offsets, and
+    // every lane then finds the cell of "its" candidate by itself -- instead of walking the cells one after another.
+    uint32_t total_cap = 0;
     uint32_t min_key = 0xFF800000u;  // sortable(+inf): nothing dropped
-    for (int s = 0; s < nseg; ++s) {
-        total_cap += (int)ccnt[(size_t)s * nq_pad + q];
-        const uint32_t t = ctau[(size_t)s * nq_pad + q];  // order-preserving keys (topk_buffer.h f2s)
-        min_key = (t < min_key) ? t : min_key;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int sg = s0 + lane;
+        const uint32_t c = sg < nseg ? ccnt[(size_t)sg * nq_pad + q] : 0u;
+        const uint32_t t = sg < nseg ? ctau[(size_t)sg * nq_pad + q] : 0xFF800000u;  // order-preserving keys (f2s)
+        uint32_t m = t, a = c;
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint32_t om = (uint32_t)__shfl_xor((int)m, d);
+            m = om < m ? om : m;
+            a += (uint32_t)__shfl_xor((int)a, d);
+        }
+        min_key = m < min_key ? m : min_key;
+        total_cap += a;
     }
     const float min_tau = __uint_as_float((min_key & 0x80000000u) ? (min_key & 0x7FFFFFFFu) : ~min_key);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sidx = skey + total_cap;
+    uint32_t *sfk = sidx + total_cap;  // the filter's keys (when given)
+    float *qs = reinterpret_cast<float *>(sfk + total_cap);  // the query row, zero padded like the corpus rows
     if (lane == 0) kth_key = KeyOf<float>::kNaN;
     const float *qrow = Q + q * ldq;
-    uint32_t n = 0;
-    for (int s = 0; s < nseg; ++s) {
-        const uint32_t c = ccnt[(size_t)s * nq_pad + q];
-        const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
-        for (uint32_t e = lane; e < c; e += 64) {
-            const uint32_t ix = cidx[(base + e) * (size_t)idx_stride];
-            sidx[n + e] = ix;
-            // a padding row (the bf16 filter may list one while a threshold is still +inf) sorts behind everything
-            skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
+    const int len = (int)((dim + 7) / 8 * 8);  // <= ldp, ldq: both are padded to a multiple of 8 with zeros
+    for (int k = lane; k < len; k += 64) qs[k] = qrow[k];
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    uint32_t n = 0, evaluated = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        // offsets of up to 64 cells (inclusive wave scan), then one candidate per lane and round
+        const int sg = s0 + lane;
+        const uint32_t c = sg < nseg ? ccnt[(size_t)sg * nq_pad + q] : 0u;
+        uint32_t inc = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, d);
+            if (lane >= d) inc += up;
         }
-        n += c;
+        __syncthreads();  // previous chunk's readers are done with seg_off / seg_cnt
+        seg_off[lane] = inc - c;
+        seg_cnt[lane] = c;
+        const uint32_t chunk_total = (uint32_t)__shfl((int)inc, 63);
+        if (lane == 0) seg_off[64] = chunk_total;
+        __syncthreads();
+        const int nsc = nseg - s0 < 64 ? nseg - s0 : 64;
+        for (uint32_t e0 = 0; e0 < chunk_total; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < chunk_total) {
+                int lo = 0, hi = nsc - 1;  // last cell whose offset is <= e (cells with zero entries are skipped by <=)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (seg_off[mid] <= e) lo = mid; else hi = mid - 1;
+                }
+                const size_t src = (((size_t)(s0 + lo) * nq_pad + q) * (size_t)cap + (e - seg_off[lo])) * (size_t)idx_stride;
+                const uint32_t ix = cidx[src];
+                sidx[n + e] = ix;
+                if (ckey) {
+                    sfk[n + e] = ckey[src];
+                    skey[n + e] = 0xFFFFFFFFu;
+                } else {
+                    // a row number beyond the corpus (never produced; defensive) sorts behind everything
+                    skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
+                }
+            }
+        }
+        n += chunk_total;
+    }
+    if (!ckey) {
+        evaluated = n;
+    } else {
+        // The filter's keys are lower bounds of the candidates' squared distances (minus |q|^2 with qn), so most
+        // candidates never need their exact distance: evaluate the kout with the smallest bounds, take the kout-th
+        // exact distance d among them, and evaluate further only the candidates whose bound does not PROVE them
+        // farther than d (same inequality as the proof below).  Unevaluated entries keep the key 0xFFFFFFFF.
+        __syncthreads();
+        bool all = n <= (uint32_t)kout;
+        uint32_t K1 = 0xFFFFFFFFu;
+        if (!all) K1 = kth_smallest_lds(sfk, n, (uint32_t)kout, lane);
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool go = e < n && (all || sfk[e] <= K1);
+            if (go) {
+                const uint32_t ix = sidx[e];
+                if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched_f32(qs, P + (size_t)ix * ldp, len));
+            }
+            evaluated += (uint32_t)__popcll(__ballot(go));
+        }
+        __syncthreads();
+        if (!all) {
+            const uint32_t dk1 = kth_smallest_lds(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
+            const bool prune = dk1 < 0x7F800000u;  // finite: else every candidate is evaluated
+            double rhs = 0.0;
+            if (prune) {
+                const double dk = (double)__uint_as_float(dk1), dn = (double)__uint_as_float(dk1 + 1);
+                const double mid = 0.5 * (dk + dn);
+                rhs = mid * mid * (1.0 + 4.5e-16);
+            }
+            const double qadd = qn ? qn[q] : 0.0;
+            for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                bool go = e < n && skey[e] == 0xFFFFFFFFu && sfk[e] > K1;
+                if (go && prune) {
+                    const uint32_t fk = sfk[e];
+                    const double L = (double)__uint_as_float((fk & 0x80000000u) ? (fk & 0x7FFFFFFFu) : ~fk);
+                    const double lb = ((L - fabs(L) * 1.9073486328125e-06) + qadd) * (1.0 - (double)(dim + 4) * u) - 1e-37;
+                    go = !(lb > rhs);  // not provably farther than the kout-th exact distance found so far
+                }
+                if (go) {
+                    const uint32_t ix = sidx[e];
+                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched_f32(qs, P + (size_t)ix * ldp, len));
+                }
+                evaluated += (uint32_t)__popcll(__ballot(go));
+            }
+        }
     }
     __syncthreads();
     const uint32_t n_all = n;
@@ -264,7 +401,6 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
             const double dn = (double)__uint_as_float(kk + 1);  // succ(d_k): next float up (d_k finite, >= +0)
             const double mid = 0.5 * (dk + dn);
             const double rhs = mid * mid * (1.0 + 4.5e-16);
-            const double u = 5.9604644775390625e-08;  // 2^-24
             // bf16 filter: the thresholds are TAGGED bounds of d2 - |q|^2 (bf16_filter.hip): within 2^-19 relative
             // of the bound itself; qn[q] <= |q|^2
             const double d2_lb = qn ? ((double)min_tau - fabs((double)min_tau) * 1.9073486328125e-06) + qn[q]
@@ -275,20 +411,49 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         if (qbad && qbad[q]) ok = false;
         flags[q] = ok ? 0u : 1u;
         if (!ok) atomicAdd(n_flagged, 1u);
-        atomicAdd(n_cand, (unsigned long long)n_all);
+        // statistics: per-query words, summed by stat_reduce_kernel (10^4 blocks adding to one address took as
+        // long as everything else in this kernel together)
+        if (qstat) {
+            qstat[2 * q] = n_all;
+            qstat[2 * q + 1] = evaluated;
+        }
+    }
+}
+
+__global__ void stat_reduce_kernel(const uint32_t *__restrict__ qstat, int nq, unsigned long long *__restrict__ n_cand,
+                                   unsigned long long *__restrict__ n_eval) {
+    unsigned long long a = 0, b = 0;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        a += qstat[2 * i];
+        b += qstat[2 * i + 1];
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(n_cand, a);
+        atomicAdd(n_eval, b);
     }
 }
 
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, uint32_t *flags, uint32_t *n_flagged,
-                                    uint64_t *n_cand, const double *qn, const uint32_t *qbad, hipStream_t s) {
-    const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 8;
+                                    uint64_t *n_cand, const double *qn, const uint32_t *qbad, uint32_t *qstat,
+                                    hipStream_t s) {
+    // with filter keys in the buffers (both MFMA tiers) candidates are evaluated lazily
+    const uint32_t *ckey = static_cast<const uint32_t *>(cb.keys);
+    const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 12 + ((size_t)dim + 8) * sizeof(float);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
-                       ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, flags, n_flagged,
-                       reinterpret_cast<unsigned long long *>(n_cand), qn, qbad, cb.idx_stride);
+                       ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, flags, n_flagged, qn, qbad,
+                       cb.idx_stride, ckey, qstat);
+    if (qstat && n_cand)  // n_cand[0] += candidates, n_cand[3] += exact evaluations
+        hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(1024), 0, s, qstat, nq,
+                           reinterpret_cast<unsigned long long *>(n_cand),
+                           reinterpret_cast<unsigned long long *>(n_cand) + 3);
     return hipGetLastError();
 }
 
