@@ -44,6 +44,9 @@ CONFIGS = {
     "c4s": (1_000_000, 768, 10_000, 10),
     "c5s": (1_000_000, 96, 10_000, 10),
     "c5shard": (12_500_000, 96, 1_000_000, 10),  # one of the 8 row shards of configs[4]
+    "c2s2": (500_000, 128, 10_000, 10),          # one shard of C2 at 2 / 4 / 8 GPUs
+    "c2s4": (250_000, 128, 10_000, 10),
+    "c2s8": (125_000, 128, 10_000, 10),
     "c5m": (1_000_000, 96, 200_000, 10),         # many queries: one workgroup per query tile
     "c3m": (1_000_000, 128, 200_000, 100),
 }
