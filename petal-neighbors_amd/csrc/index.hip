@@ -530,7 +530,7 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // benign data (the bound is loose by a few percent of the distance spread).  The proof needs every segment's
 // k'-th bound to clear that distance, i.e. k' above the number of those R rows that fall into one segment:
 //   level 0 (default): rows in arbitrary order -- a segment holds Poisson(R / segments) of them, k' is that mean
-//            plus six standard deviations; a query tile served by fewer than 4 workgroups is split into row
+//            plus five standard deviations + 3; a query tile served by fewer than 4 workgroups is split into row
 //            parts so that small buffers suffice;
 //   level 1: all R rows may sit in one segment (corpus sorted by cluster): k' = R + 6 sqrt(R);
 //   level 2: tier off.
@@ -561,7 +561,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
         if (ix->filter_slots > 0) return (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
         if (ix->bf16_level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
         const double per = R / (double)(per_tile * (size_t)split);
-        const double v = per + 6.0 * std::sqrt(per) + 4.0;
+        const double v = per + 5.0 * std::sqrt(per) + 3.0;  // ~1e-6 per (query, segment) of holding more than that
         return v < 8.0 ? 8.0 : v;
     };
     // split the rows of a query tile into parts only while one buffer would need more than 128 slots
