@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         // ---- scout pass.  A buffer that starts from tau = +inf admits ~k' ln(n/k') rows before its threshold
         // has converged, and with 2048 waves x 64 buffers warming up at once those appends, not the MFMAs, set
         // the kernel's time.  So the first t tiles of the run are first contracted WITHOUT buffers: each lane
-        // keeps the 4 smallest of its block minima (16 rows each); the 4th smallest, over both lane halves, is
+        // keeps the 4 smallest of its block minima (16 rows each); the 4th smallest of both lane halves' lists is
         // the starting threshold of the real pass (about the 1e-3 quantile of the segment's bounds: ~30x fewer
         // rows pass it than pass a cold buffer, and it is far above the k-th neighbour's bound).  ANY starting
         // value is valid -- rows are only ever dropped against the threshold that is finally reported -- a
@@ -556,8 +556,15 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             }
             insert4(s0, m0);
             insert4(s1, m1);
-            tau0 = fminf(s0[3], __shfl_xor(s0[3], 32));
-            tau1 = fminf(s1[3], __shfl_xor(s1[3], 32));
+            // 4th smallest of the UNION of the two lane halves' lists (both sorted ascending):
+            // min(b4, max(a1,b3), max(a2,b2), max(a3,b1), a4)
+            auto union4 = [](const float (&a)[4]) {
+                const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
+                            b4 = __shfl_xor(a[3], 32);
+                return fminf(fminf(fminf(a[3], b4), fminf(fmaxf(a[0], b3), fmaxf(a[2], b1))), fmaxf(a[1], b2));
+            };
+            tau0 = union4(s0);
+            tau1 = union4(s1);
         }
         uint2 *ce_blk0 = cand + cell0 * CAP;              // query block 0: 32 buffers
         uint2 *ce_blk1 = ce_blk0 + (size_t)32 * CAP;      // query block 1
