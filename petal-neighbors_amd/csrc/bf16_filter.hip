@@ -749,7 +749,7 @@ static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, bool radius, hipStream_t s) {
     if (radius)
-        return cb.cap == 128 && tau_init ? launch_bf16_t<KS, 2, true>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp,
+        return cb.cap == 256 && tau_init ? launch_bf16_t<KS, 4, true>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp,
                                                                       scout_max, tau_init, s)
                                          : hipErrorInvalidValue;
     switch (cb.cap) {

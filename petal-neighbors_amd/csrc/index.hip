@@ -1014,7 +1014,7 @@ static int radius_finish(const pn_index *ix, size_t nq, size_t kept_stride, uint
 static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
                        uint64_t **idx_out, bool *done, hipStream_t s) {
     *done = false;
-    const int cap = 128;  // up to 96 rows within the radius per (segment, query) before the call overflows
+    const int cap = 256;  // up to 224 rows within the radius per (segment, query) before the call overflows
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
     size_t n_wg = (size_t)ix->n_cu * 2;
     size_t cap_wg = q_tiles * 32;

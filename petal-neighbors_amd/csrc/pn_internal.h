@@ -156,7 +156,7 @@ hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, in
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);
 // tau_init (nullable, [nq_pad] sortable keys): starting thresholds instead of the scout pass.  radius = true:
-// fixed thresholds (tau_init required, cb.cap == 128), buffers overflow (count = cap + 1) instead of compacting
+// fixed thresholds (tau_init required, cb.cap == 256), buffers overflow (count = cap + 1) instead of compacting
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s);
 hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);
