@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         // ---- scout pass.  A buffer that starts from tau = +inf admits ~k' ln(n/k') rows before its threshold
         // has converged, and with 2048 waves x 64 buffers warming up at once those appends, not the MFMAs, set
         // the kernel's time.  So the first t tiles of the run are first contracted WITHOUT buffers: each lane
-        // keeps the 4 smallest of its block minima (16 rows each); the 4th smallest of both lane halves' lists is
+        // keeps the 5 smallest of its block minima (16 rows each); the 5th smallest of both lane halves' lists is
         // the starting threshold of the real pass (about the 1e-3 quantile of the segment's bounds: ~30x fewer
         // rows pass it than pass a cold buffer, and it is far above the k-th neighbour's bound).  ANY starting
         // value is valid -- rows are only ever dropped against the threshold that is finally reported -- a
@@ -511,15 +511,17 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #endif
         if (t_scout) {
             const float inf = __uint_as_float(0x7F800000u);
-            float s0[4] = {inf, inf, inf, inf}, s1[4] = {inf, inf, inf, inf};
-            auto insert4 = [](float (&l)[4], float x) {
+            float s0[5] = {inf, inf, inf, inf, inf}, s1[5] = {inf, inf, inf, inf, inf};
+            auto insert5 = [](float (&l)[5], float x) {  // keep the five smallest, ascending
                 float t = fmaxf(l[0], x);
                 l[0] = fminf(l[0], x);
                 float u = fmaxf(l[1], t);
                 l[1] = fminf(l[1], t);
                 t = fmaxf(l[2], u);
                 l[2] = fminf(l[2], u);
+                u = fmaxf(l[3], t);
                 l[3] = fminf(l[3], t);
+                l[4] = fminf(l[4], u);
             };
             __syncthreads();
             dma_tile(rt0, 0);
@@ -541,11 +543,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 if (rt + 1 < rt0 + t_scout) dma_tile(rt + 1, cs ^ 1);
                 float m0, m1;
                 bf_chain<KS, false>(arow0, pre0, b0, b1, x00, x01, x10, x11, m0, m1);
-                insert4(s0, m0);
-                insert4(s1, m1);
+                insert5(s0, m0);
+                insert5(s1, m1);
                 bf_chain<KS, false>(arow1, pre1, b0, b1, x10, x11, x00, x01, m0, m1);
-                insert4(s0, m0);
-                insert4(s1, m1);
+                insert5(s0, m0);
+                insert5(s1, m1);
                 __syncthreads();
             }
             float m0 = x10[0], m1 = x11[0];
@@ -554,17 +556,18 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m0 = fminf(m0, x10[i]);
                 m1 = fminf(m1, x11[i]);
             }
-            insert4(s0, m0);
-            insert4(s1, m1);
-            // 4th smallest of the UNION of the two lane halves' lists (both sorted ascending):
-            // min(b4, max(a1,b3), max(a2,b2), max(a3,b1), a4)
-            auto union4 = [](const float (&a)[4]) {
+            insert5(s0, m0);
+            insert5(s1, m1);
+            // 5th smallest of the UNION of the two lane halves' lists (both sorted ascending):
+            // min(b5, max(a1,b4), max(a2,b3), max(a3,b2), max(a4,b1), a5)
+            auto union5 = [](const float (&a)[5]) {
                 const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
-                            b4 = __shfl_xor(a[3], 32);
-                return fminf(fminf(fminf(a[3], b4), fminf(fmaxf(a[0], b3), fmaxf(a[2], b1))), fmaxf(a[1], b2));
+                            b4 = __shfl_xor(a[3], 32), b5 = __shfl_xor(a[4], 32);
+                const float x = fminf(fminf(a[4], b5), fminf(fmaxf(a[0], b4), fmaxf(a[3], b1)));
+                return fminf(x, fminf(fmaxf(a[1], b3), fmaxf(a[2], b2)));
             };
-            tau0 = union4(s0);
-            tau1 = union4(s1);
+            tau0 = union5(s0);
+            tau1 = union5(s1);
         }
         uint2 *ce_blk0 = cand + cell0 * CAP;              // query block 0: 32 buffers
         uint2 *ce_blk1 = ce_blk0 + (size_t)32 * CAP;      // query block 1
