@@ -243,6 +243,7 @@ __device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, i
 // rare path needs no search.  The filter then works on these tagged values throughout (comparison, stored key,
 // threshold); they differ from the bounds by less than 2^-19 relative, which the proof in select.hip subtracts.
 constexpr int kLA = 3;
+constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
 template <int KS, bool EMB>
 __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
                                          const bf16x8 (&b1)[KS], f32x16 &w0, f32x16 &w1, f32x16 &r0, f32x16 &r1,
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                                                              uint32_t *__restrict__ ctau, size_t nq_pad,
                                                              uint32_t split, uint32_t seg_per_part,
                                                              uint32_t scout_max,
-                                                             const uint32_t *__restrict__ tau_init) {
+                                                             const uint32_t *__restrict__ tau_init,
+                                                             float *__restrict__ scout_out) {
     constexpr int C = 2 * KS, CP = C + 1;
     constexpr uint32_t CAP = 64u * M;
     constexpr int TB = kBP * CP * 16;  // bytes per tile image
@@ -509,19 +511,23 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             tau1 = s2f(tau_init[q0 + 32 + jq]);
         }
 #endif
+        if (scout_out) {  // scout-only launch: every run contributes its lists, however short it is
+            t_scout = run_len < scout_max ? run_len : scout_max;
+            if (t_scout < 1u) t_scout = 1u;
+        }
         if (t_scout) {
             const float inf = __uint_as_float(0x7F800000u);
-            float s0[5] = {inf, inf, inf, inf, inf}, s1[5] = {inf, inf, inf, inf, inf};
-            auto insert5 = [](float (&l)[5], float x) {  // keep the five smallest, ascending
-                float t = fmaxf(l[0], x);
-                l[0] = fminf(l[0], x);
-                float u = fmaxf(l[1], t);
-                l[1] = fminf(l[1], t);
-                t = fmaxf(l[2], u);
-                l[2] = fminf(l[2], u);
-                u = fmaxf(l[3], t);
-                l[3] = fminf(l[3], t);
-                l[4] = fminf(l[4], u);
+            float s0[kScoutList], s1[kScoutList];
+#pragma unroll
+            for (int i = 0; i < kScoutList; ++i) { s0[i] = inf; s1[i] = inf; }
+            auto insert = [](float (&l)[kScoutList], float x) {  // keep the kScoutList smallest, ascending
+                float c = x;
+#pragma unroll
+                for (int i = 0; i < kScoutList; ++i) {
+                    const float lo = fminf(l[i], c);
+                    c = fmaxf(l[i], c);
+                    l[i] = lo;
+                }
             };
             __syncthreads();
             dma_tile(rt0, 0);
@@ -543,11 +549,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 if (rt + 1 < rt0 + t_scout) dma_tile(rt + 1, cs ^ 1);
                 float m0, m1;
                 bf_chain<KS, false>(arow0, pre0, b0, b1, x00, x01, x10, x11, m0, m1);
-                insert5(s0, m0);
-                insert5(s1, m1);
+                insert(s0, m0);
+                insert(s1, m1);
                 bf_chain<KS, false>(arow1, pre1, b0, b1, x10, x11, x00, x01, m0, m1);
-                insert5(s0, m0);
-                insert5(s1, m1);
+                insert(s0, m0);
+                insert(s1, m1);
                 __syncthreads();
             }
             float m0 = x10[0], m1 = x11[0];
@@ -556,11 +562,23 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m0 = fminf(m0, x10[i]);
                 m1 = fminf(m1, x11[i]);
             }
-            insert5(s0, m0);
-            insert5(s1, m1);
+            insert(s0, m0);
+            insert(s1, m1);
+            if (scout_out) {
+                // publish this lane's lists: [cell][half][kScoutList]; bf16_seed_kernel merges the cells of a query
+                float *o0 = scout_out + ((cell0 + jq) * 2 + h) * kScoutList;
+                float *o1 = scout_out + ((cell0 + 32 + jq) * 2 + h) * kScoutList;
+#pragma unroll
+                for (int i = 0; i < kScoutList; ++i) {
+                    o0[i] = s0[i];
+                    o1[i] = s1[i];
+                }
+                u0 = run_end;
+                continue;
+            }
             // 5th smallest of the UNION of the two lane halves' lists (both sorted ascending):
             // min(b5, max(a1,b4), max(a2,b3), max(a3,b2), max(a4,b1), a5)
-            auto union5 = [](const float (&a)[5]) {
+            auto union5 = [](const float (&a)[kScoutList]) {
                 const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
                             b4 = __shfl_xor(a[3], 32), b5 = __shfl_xor(a[4], 32);
                 const float x = fminf(fminf(a[4], b5), fminf(fmaxf(a[0], b4), fmaxf(a[3], b1)));
@@ -731,7 +749,7 @@ hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, in
 template <int KS, int M, bool RAD>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                const uint32_t *tau_init, hipStream_t s) {
+                                const uint32_t *tau_init, float *scout_out, hipStream_t s) {
     const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
     auto kern = bf16_filter_kernel<KS, M, RAD>;
     static bool attr_done = false;
@@ -743,25 +761,28 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,
                        static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,
-                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init);
+                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out);
     return hipGetLastError();
 }
 
 template <int KS>
 static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                const uint32_t *tau_init, bool radius, hipStream_t s) {
+                                const uint32_t *tau_init, bool radius, float *scout_out, hipStream_t s) {
     if (radius)
         return cb.cap == 256 && tau_init ? launch_bf16_t<KS, 4, true>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp,
-                                                                      scout_max, tau_init, s)
+                                                                      scout_max, tau_init, nullptr, s)
                                          : hipErrorInvalidValue;
     switch (cb.cap) {
         case 64:
-            return launch_bf16_t<KS, 1, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
+            return launch_bf16_t<KS, 1, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
+                                               scout_out, s);
         case 128:
-            return launch_bf16_t<KS, 2, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
+            return launch_bf16_t<KS, 2, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
+                                               scout_out, s);
         case 256:
-            return launch_bf16_t<KS, 4, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init, s);
+            return launch_bf16_t<KS, 4, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
+                                               scout_out, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -774,7 +795,8 @@ int bf16_segments(size_t q_tiles, int n_wg, int split) {
 }
 
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
-                              int split, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s) {
+                              int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                              hipStream_t s) {
     if (!bf16_supported(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
         cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0)
         return hipErrorInvalidValue;
@@ -785,17 +807,54 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     if (cb.nseg < (int)(spp * split)) return hipErrorInvalidValue;
     const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
     switch (bf16_ks_for(dim)) {
-        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
-        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, s);
+        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
         default: return hipErrorInvalidValue;
     }
 }
+
+// Shared scout (few queries, many segments per query): a scout-only launch leaves, per (segment, query) cell and
+// lane half, the kScoutList smallest block minima of that segment's first tiles.  The rows scouted by ALL segments
+// of a query form one sample of the corpus; its rank-th smallest bound is a far better starting threshold for every
+// segment than each segment's own list could give (rank from the host: the sample holds Poisson(lambda) of the rows
+// that matter, the seed must stay above them).  out[q] = sortable key just above that bound.  One wave per query.
+__global__ __launch_bounds__(64) void bf16_seed_kernel(const float *__restrict__ lists, size_t nq_pad, int nseg,
+                                                       uint32_t rank, uint32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *sk = reinterpret_cast<uint32_t *>(smem_raw);
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const uint32_t per = 2 * kScoutList, n = (uint32_t)nseg * per;
+    for (uint32_t e = lane; e < n; e += 64)
+        sk[e] = f2s(lists[((size_t)(e / per) * nq_pad + q) * per + e % per]);
+    __syncthreads();
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cnd = T | (1u << bit);
+        uint32_t c = 0;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            c += (uint32_t)__popcll(__ballot(e < n && sk[e] < cnd));
+        }
+        if (c < rank) T = cnd;
+    }
+    if (lane == 0) out[q] = T == 0xFFFFFFFFu ? T : T + 1;  // rows with a bound EQUAL to it still pass the strict '<'
+}
+
+hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s) {
+    const size_t sh = (size_t)nseg * 2 * kScoutList * sizeof(uint32_t);
+    if (sh > 64 * 1024 || rank < 1 || (size_t)rank > (size_t)nseg * 2 * kScoutList) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bf16_seed_kernel, dim3((unsigned)nq_pad), dim3(64), sh, s, lists, nq_pad, nseg, (uint32_t)rank,
+                       out);
+    return hipGetLastError();
+}
+int bf16_scout_list() { return kScoutList; }
 
 // radius queries: per-query threshold of the filter.  A row can only be within the radius when its exact squared
 // distance is below tau_r (computed by the host with the rounding allowances of select.hip's proof), hence when

@@ -119,7 +119,7 @@ struct pn_index {
     mutable std::mutex mu;
     mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
     mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
-    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed, w_qstat;  // bf16 tier
+    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed, w_qstat, w_lists;  // bf16 tier
     mutable pn_stats stats{};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
@@ -325,7 +325,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
                       &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
                       &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo,
                       &ix->w_bq, &ix->w_qn, &ix->w_qbad, &ix->w_bflags, &ix->w_gq, &ix->w_gidx, &ix->w_gdist,
-                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed, &ix->w_qstat};
+                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed, &ix->w_qstat, &ix->w_lists};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
@@ -538,6 +538,9 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 struct Bf16Plan {
     int n_wg, split, nseg, kp, cap, scout_max;
     bool ok;
+    // shared scout (several segments per query): scout-only launch, merged seed of rank seed_rank, main launch
+    bool shared_scout;
+    int scout_tiles, seed_rank;
 };
 static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     Bf16Plan p{};
@@ -577,6 +580,34 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     // scouted rows should hold < 0.1 of the R relevant rows in expectation: tiles <= N / (10 R) / 64
     const double sm = (double)r_tiles / (10.0 * R);
     p.scout_max = sm > 64.0 ? 64 : (int)sm;
+    // Shared scout: with S >= 2 segments per query the rows scouted by all S workgroups of a query tile are ONE
+    // sample, S times larger than a workgroup's own, and its seed_rank-th smallest bound starts every segment near
+    // the quantile its threshold would only reach at the end of its run.  lambda = expected number of the R
+    // relevant rows inside the sample (kept <= 1.2); the seed must stay above them: seed_rank = smallest rank with
+    // P(Poisson(lambda) >= rank) <= 1e-7 (a seed that is too low only sends the query to the next tier).
+    p.shared_scout = false;
+#ifndef PN_DIAG_NO_SHARED_SCOUT
+    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && p.split == 1 && per_tile >= 2 &&
+        p.n_wg % (int)q_tiles == 0) {
+        const size_t run_len = r_tiles / per_tile;
+        double t = 1.2 * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup for lambda = 1.2
+        if (t > 64.0) t = 64.0;
+        if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
+        p.scout_tiles = (int)t;
+        if (p.scout_tiles >= 4) {
+            const double lam = R * (double)p.scout_tiles * (double)per_tile / (double)r_tiles;
+            double term = std::exp(-lam), cdf = term;  // P(X <= 0)
+            int rank = 1;
+            while (1.0 - cdf > 1e-7 && rank < 2 * bf16_scout_list()) {  // 1 - cdf = P(X >= rank)
+                term *= lam / (double)rank;
+                cdf += term;
+                ++rank;
+            }
+            p.seed_rank = rank < 5 ? 5 : rank;
+            p.shared_scout = p.seed_rank <= bf16_scout_list();
+        }
+    }
+#endif
     return p;
 }
 static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
@@ -769,8 +800,20 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, plan.split,
-                              plan.scout_max, nullptr, false, s));
+    if (plan.shared_scout) {
+        const size_t words = cells * 2 * (size_t)bf16_scout_list();
+        PNCHK(ix->w_lists.ensure(words * sizeof(float)));
+        PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
+                                  nullptr, false, (float *)ix->w_lists.p, s));
+        HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, 0,
+                                  (const uint32_t *)ix->w_seed.p, false, nullptr, s));
+    } else {
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, plan.split,
+                                  plan.scout_max, nullptr, false, nullptr, s));
+    }
     if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_bflags.p, d_nflag,
@@ -1049,7 +1092,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     HIPCHK(launch_bf16_radius_tau((const double *)ix->w_qn.p, nq_pad, t, (uint32_t *)ix->w_seed.p, s));
     CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
     HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
-                              (const uint32_t *)ix->w_seed.p, true, s));
+                              (const uint32_t *)ix->w_seed.p, true, nullptr, s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                    (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2, s));

@@ -157,8 +157,14 @@ hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, in
 int bf16_segments(size_t q_tiles, int n_wg, int split);
 // tau_init (nullable, [nq_pad] sortable keys): starting thresholds instead of the scout pass.  radius = true:
 // fixed thresholds (tau_init required, cb.cap == 256), buffers overflow (count = cap + 1) instead of compacting
+// scout_out (nullable): scout-only launch -- no buffers are touched; every run leaves its lanes' smallest block
+// minima in scout_out[cell][2][bf16_scout_list()] (pre-filled with +inf by the caller)
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
-                              int split, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s);
+                              int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                              hipStream_t s);
+int bf16_scout_list();
+// out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
+hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);
 hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);
 // diagnostic: out[q][row] = L'(q, row), q < nq, row < n_rows
 hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
