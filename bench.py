@@ -189,7 +189,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = nq * args.steps / elapsed
-        # dominant kernel: one launch covers all nq queries against this rank's shard
+        # dominant kernel: its launches of one step together cover all nq queries against this rank's shard (the bf16
+        # tier launches it twice per step: a short scout launch and the main launch); achieved = algorithmic flops of
+        # a step / the kernel's time in a step = flops per launch / mean launch duration
         launches = max(int(st["hot_launches"]), 1)
         hot_ms = st["hot_ms"] / launches
         # 2*N*D flop per query; a step of more than 262 144 queries is served in several launches
@@ -230,6 +232,8 @@ def main():
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "kernel": kernel_name, "mfma_dtype": "bf16" if engine_used == "bf16" else "f32",
                          "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
+                         "launches_per_step": round(launches / max(args.steps, 1), 2),
+                         "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4),
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
                                                   / (peak * world), 4)},
             "fallback_queries": int(st["fallback_queries"]),

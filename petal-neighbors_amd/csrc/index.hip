@@ -121,7 +121,7 @@ struct pn_index {
     mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
     mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed, w_qstat, w_lists;  // bf16 tier
     mutable pn_stats stats{};
-    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr, ev5 = nullptr;
 };
 
 struct DeviceGuard {
@@ -330,7 +330,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
-    hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3};
+    hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3, ix->ev4, ix->ev5};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -431,6 +431,8 @@ static int ensure_events(const pn_index *ix) {
     HIPCHK(hipEventCreate(&ix->ev1));
     HIPCHK(hipEventCreate(&ix->ev2));
     HIPCHK(hipEventCreate(&ix->ev3));
+    HIPCHK(hipEventCreate(&ix->ev4));
+    HIPCHK(hipEventCreate(&ix->ev5));
     return PN_OK;
 }
 
@@ -807,7 +809,9 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
                                   nullptr, false, (float *)ix->w_lists.p, s));
+        if (prof) HIPCHK(hipEventRecord(ix->ev4, s));  // the dominant kernel runs twice per call: both are timed
         HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
+        if (prof) HIPCHK(hipEventRecord(ix->ev5, s));
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, 0,
                                   (const uint32_t *)ix->w_seed.p, false, nullptr, s));
     } else {
@@ -824,9 +828,17 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(hipStreamSynchronize(s));
     if (prof) {
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        if (plan.shared_scout) {  // scout launch ev0..ev4, main launch ev5..ev1 (the seed kernel in between is not counted)
+            float a = 0, b = 0;
+            HIPCHK(hipEventElapsedTime(&a, ix->ev0, ix->ev4));
+            HIPCHK(hipEventElapsedTime(&b, ix->ev5, ix->ev1));
+            ms = a + b;
+            ix->stats.hot_launches += 2;
+        } else {
+            HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            ix->stats.hot_launches += 1;
+        }
         ix->stats.hot_ms += ms;
-        ix->stats.hot_launches += 1;
     }
     ix->stats.candidates += h.ncand;
     ix->stats.evaluations += h.neval;
