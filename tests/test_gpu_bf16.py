@@ -70,33 +70,26 @@ def test_lower_bound_inequality(pn, name, dim):
         assert gap.max() < 0.05 * d2.mean() + 1e-3
 
 
-@pytest.mark.parametrize("dim", [16, 128])
-def test_accumulation_error_within_allowance(pn, dim):
-    """|MFMA result - exact sum of its bf16 terms| against g * (sum of magnitudes): the proof assumes ratio <= 1
-    with g = 2^-13; the measured ratio is reported so a regression in margin is visible."""
-    n, nq = 2048, 64
-    pts = (uniform((n, dim), 21) - np.float32(0.5)) * np.float32(3.0)
-    qs = (uniform((nq, dim), 22) - np.float32(0.5)) * np.float32(3.0)
+@pytest.mark.parametrize("name", ["centered", "offset1000", "mixed_scales", "uniform"])
+@pytest.mark.parametrize("dim", [16, 100, 128])
+def test_matrix_core_accumulation_error_is_far_inside_the_allowance(pn, name, dim):
+    """The one hardware assumption of the bound: |value delivered by v_mfma_f32_32x32x16_bf16 - exact sum of its
+    bf16 x bf16 terms| <= g * sum|terms| with g = 2^-13.  The terms are rebuilt bit for bit on the host
+    (tests/test_bf16_bound_model.py holds the same constants and roundings as the pack kernels), summed in f64, and
+    compared with what the GPU returned."""
+    from test_bf16_bound_model import corpus_columns, query_columns, G
+    n, nq = 1024, 64
+    pts = CASES[name](n, dim, 21)
+    qs = CASES[name](nq, dim, 22)
     tree = pn.BallTree.euclidean(pts)
-    L, qn = _bounds(pn, tree, qs, n)
-    ph, qh = _bf16_round(pts).astype(np.float64), _bf16_round(qs).astype(np.float64)
-    p64, q64 = pts.astype(np.float64), qs.astype(np.float64)
-    g = 2.0 ** -13
-    # lower / upper envelopes of the exact sum of the bf16 terms (the extra columns are rounded outward by at
-    # most 2^-7 relative each; the data columns are exact)
-    pn_ = (p64 * p64).sum(1)
-    dot = qh @ ph.T
-    ep, eq = np.sqrt(((p64 - ph) ** 2).sum(1)), np.sqrt(((q64 - qh) ** 2).sum(1))
-    nph, nqh, npp = np.sqrt((ph * ph).sum(1)), np.sqrt((qh * qh).sum(1)), np.sqrt(pn_)
-    slack = nqh[:, None] * (2 * ep + 2 * g * nph)[None, :] + eq[:, None] * (2 * npp)[None, :]
-    hi = pn_[None, :] - 2 * dot - slack                                  # every outward rounding at its least
-    lo = pn_[None, :] * (1 - g) * (1 - 2.0 ** -21) - 2 * dot - slack * (1 + 2 * g) * (1 + 2.0 ** -7) ** 2
-    mag = pn_[None, :] + 2 * np.abs(qh) @ np.abs(ph).T + slack * 1.02
-    over = (L.astype(np.float64) - hi) / (g * mag)   # > 0 only through accumulation error
-    under = (lo - L.astype(np.float64)) / (g * mag)
-    worst = max(over.max(), under.max())
-    print(f"D={dim}: accumulation error / allowance = {worst:.4f}")
-    assert worst < 0.25, f"matrix-core accumulation error uses {worst:.2f} of the allowance (expected < 0.25)"
+    L, _ = _bounds(pn, tree, qs, n)
+    ph, pieces, bp, dp = corpus_columns(pts)
+    mq, aq, cq, _ = query_columns(qs)
+    exact = pieces.sum(1)[None, :] + mq @ ph.T - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
+    mags = pieces.sum(1)[None, :] + np.abs(mq) @ np.abs(ph).T + aq[:, None] * bp[None, :] + cq[:, None] * dp[None, :]
+    ratio = np.abs(L.astype(np.float64) - exact) / (G * mags)
+    print(f"{name}/D={dim}: accumulation error / allowance: max {ratio.max():.4f}, mean {ratio.mean():.5f}")
+    assert ratio.max() < 0.1, f"matrix-core accumulation error uses {ratio.max():.3f} of the allowance"
 
 
 def _check(pn, oracle_mod, pts, qs, k, opts=None, expect_fallback=None):
