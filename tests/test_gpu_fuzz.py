@@ -1,0 +1,18 @@
+"""Randomised parity sweep (tools/fuzz_knn.py): the auto engine with all its tiers against the oracle's brute
+force, bit-exact, over random shapes and data families (uniform, centred, tight clusters, duplicates, sorted rows)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_shapes_match_the_oracle(pn, oracle_mod, seed):
+    import fuzz_knn
+    rng = np.random.default_rng(seed)
+    for c in range(6):
+        assert fuzz_knn.run_case(100 * seed + c, rng)

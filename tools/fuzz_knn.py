@@ -1,0 +1,48 @@
+"""Randomised parity sweep on the GPU: auto engine (all tiers) vs the oracle's brute force, bit-exact.
+usage: fuzz_knn.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+import oracle  # noqa: E402
+import petal_neighbors_amd as pn  # noqa: E402
+from conftest import uniform  # noqa: E402
+
+
+def run_case(c, rng):
+    n = int(rng.choice([4096, 5000, 9000, 20000, 33000, 60000]))
+    dim = int(rng.choice([8, 15, 16, 31, 64, 96, 100, 128]))
+    nq = int(rng.choice([1, 7, 64, 255, 256, 257, 600, 1300]))
+    k = int(rng.choice([1, 2, 5, 10, 33, 100]))
+    kind = rng.choice(["uniform", "centered", "clustered", "dups", "sorted"])
+    pts = uniform((n, dim), 1000 + c)
+    if kind == "centered":
+        pts = pts - np.float32(0.5)
+    elif kind == "clustered":
+        cen = uniform((12, dim), 7 + c) * np.float32(4)
+        pts = (cen[rng.integers(0, 12, n)] + np.float32(0.05) * (uniform((n, dim), 99 + c) - np.float32(0.5))).astype(np.float32)
+    elif kind == "dups":
+        pts[n // 2:] = pts[: n - n // 2]
+    elif kind == "sorted":
+        pts = pts[np.argsort(pts[:, 0])]
+    qs = pts[rng.integers(0, n, nq)] + np.float32(0.01) * (uniform((nq, dim), 5000 + c) - np.float32(0.5)) if kind != "uniform" else uniform((nq, dim), 5000 + c)
+    qs = np.ascontiguousarray(qs, dtype=np.float32)
+    t = pn.BallTree.euclidean(pts)
+    idx, dist = t.query_batch(qs, k)
+    oi, od = oracle.brute_knn(pts, qs, k)
+    ok = dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)
+    st = t.stats()
+    print(f"case {c}: n={n} D={dim} nq={nq} k={k} {kind}: {'ok' if ok else 'MISMATCH'} fallback {st['fallback_queries']}/{st['queries']} cand/q {st['candidates']/max(st['queries'],1):.0f}", flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = sum(0 if run_case(c, rng) else 1 for c in range(cases))
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
