@@ -192,11 +192,12 @@ int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_pa
 
 /* ---- diagnostic: the first-tier filter's lower bounds themselves.  bounds_out[q * n_rows + i] = L'(q, p_i)
  * for the first n_rows corpus rows (clamped to n_points), with L' + qnorm_out[q] <= |q - p_i|^2 in real
- * arithmetic and qnorm_out[q] <= |q|^2 (petal-neighbors_amd/csrc/bf16_filter.hip states the bound).  Host
- * pointers; q_cols must equal the index dimension.  Not part of the reference's interface: tests use it to check
- * the inequality and to measure the matrix core's accumulation error against the allowance the proof makes. */
+ * arithmetic; qnorm_out[q] <= |q - mu|^2 where mu (mu_out, n_cols floats, nullable) is the translation vector the
+ * tier works with -- the corpus mean (petal-neighbors_amd/csrc/bf16_filter.hip states the bound).  Host pointers;
+ * q_cols must equal the index dimension.  Not part of the reference's interface: tests use it to check the
+ * inequality and to measure the matrix core's accumulation error against the allowance the proof makes. */
 int pn_bf16_bounds_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
-                       ptrdiff_t q_row_stride, size_t n_rows, float *bounds_out, double *qnorm_out);
+                       ptrdiff_t q_row_stride, size_t n_rows, float *bounds_out, double *qnorm_out, float *mu_out);
 
 /* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
  * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in

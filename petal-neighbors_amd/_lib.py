@@ -68,7 +68,7 @@ SIGNATURES = {
     "pn_distance_to_rdistance_f64": (C.c_double, [C.c_double]),
     "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
-    "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
+    "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp, _vp]),
 }
 
 _lib = None

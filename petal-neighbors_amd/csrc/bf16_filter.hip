@@ -6,6 +6,12 @@
 // f32 engines.  Only the filter's COST depends on how tight the bound is.
 //
 // ---- the bound ------------------------------------------------------------------------------------
+// Everything below is written for TRANSLATED vectors q := q - mu, p := p - mu (mu = per-dimension mean of the
+// corpus, f32, kept with the index -- or zero when translating would shrink the squared norms by less than 16x):
+// distances do not change, the norms that the bound's slack is proportional to shrink, and data with a large
+// common offset becomes servable at all.  (Mild cases are left alone on purpose: on uniform [0,1) data the
+// translation tightens the bound 4x but the signed operands cost the matrix pipe 4 % of its clock.)  The subtraction is
+// done in f64; its rounding (2^-53 relative per coordinate) disappears in the 2^-40 the norm sums are widened by.
 // q^ = bf16(q), p^ = bf16(p) (round to nearest; |x| < 2^-60 -> 0 so no product is subnormal),
 // eq = q - q^, ep = p - p^.  Then q.p = q^.p^ + q^.ep + eq.p  <=  q^.p^ + |q^||ep| + |eq||p|, so
 //     |q-p|^2 - |q|^2  =  |p|^2 - 2 q.p  >=  |p|^2 - 2 q^.p^ - 2|q^||ep| - 2|eq||p|.
@@ -20,7 +26,7 @@
 // on the host: at most 0.16 % of this allowance.
 // The magnitudes are bounded by |p|^2 + 2|q^||p^| + Aq Bp + Cq Dp, each of which is paid for above
 // (the (1-g), the 2g|p^| inside Bp, and the (1+2g) factors), so the computed value L' satisfies
-//     L'(q,p)  <=  |q-p|^2 - |q|^2     for every finite q, p with |q|^2, |p|^2 < 2^100.
+//     L'(q,p)  <=  |q-p|^2 - |q-mu|^2     for every finite q, p with |q-mu|^2, |p-mu|^2 < 2^100.
 // Rows / queries outside that range raise a flag (index not eligible / query re-run exactly).
 // Padding rows carry n_hi = 1.7e38: they can enter a buffer only while its threshold is still +inf, are the
 // first to be compacted away, and select.hip ignores row numbers >= n.
@@ -89,8 +95,9 @@ __device__ __forceinline__ uint16_t bf_up(float x) {  // x >= 0: smallest bf16 >
 
 // One thread per (padded) corpus row: bf16 row + the five extra columns, written into the tile image.
 // img: [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
-__global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, size_t n, int dim, size_t ld, int KS,
-                                        uint16_t *__restrict__ img, size_t n_rows_img, uint32_t *__restrict__ bad) {
+__global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
+                                        size_t ld, int KS, uint16_t *__restrict__ img, size_t n_rows_img,
+                                        uint32_t *__restrict__ bad) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows_img) return;
     const int CP = 2 * KS + 1;
@@ -107,11 +114,13 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, size_t n, i
     for (int k = 0; k < dim; ++k) {
         const float x = src[k];
         finite = finite && (fabsf(x) < 1.0e30f);  // also false for NaN
-        const uint16_t hb = (fabsf(x) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(x);  // 2^-60
+        const double c = (double)x - (double)mu[k];  // centred coordinate (header: translation)
+        const float cf = (float)c;
+        const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);  // 2^-60
         const float xh = bf_f(hb);
         row[k] = hb;
-        pn += (double)x * (double)x;
-        const double e = (double)x - (double)xh;
+        pn += c * c;
+        const double e = c - (double)xh;
         en += e * e;
         hn += (double)xh * (double)xh;
     }
@@ -136,9 +145,9 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, size_t n, i
 }
 
 // One thread per (padded) query: bf16 B row [K] (chunk c at 8c), |q|^2 rounded down (f64), flag.
-__global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, size_t nq, size_t nq_pad, int dim, size_t ld,
-                                         int KS, uint16_t *__restrict__ B, double *__restrict__ qn,
-                                         uint32_t *__restrict__ qbad) {
+__global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
+                                         size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
+                                         double *__restrict__ qn, uint32_t *__restrict__ qbad) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
     const int K = 16 * KS, E = 16 * (KS - 1);
@@ -151,11 +160,13 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, size_t nq,
         for (int k = 0; k < dim; ++k) {
             const float x = src[k];
             finite = finite && (fabsf(x) < 1.0e30f);
-            const uint16_t hb = (fabsf(x) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(x);
+            const double c = (double)x - (double)mu[k];
+            const float cf = (float)c;
+            const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const float xh = bf_f(hb);
             row[k] = bf_rne(-2.0f * xh);  // exact: a power-of-two multiple of a bf16 value
-            s += (double)x * (double)x;
-            const double e = (double)x - (double)xh;
+            s += c * c;
+            const double e = c - (double)xh;
             en += e * e;
             hn += (double)xh * (double)xh;
         }
@@ -732,17 +743,39 @@ int bf16_cap_for(int kp) { return kp <= 16 ? 64 : kp <= 64 ? 128 : 256; }
 #endif
 int bf16_query_tile() { return kBQ; }
 
-hipError_t launch_bf16_pack_corpus(const float *P, size_t n, int dim, size_t ld, void *img, uint32_t *bad,
-                                   hipStream_t s) {
+// per-dimension sums of the corpus in f64 (any translation vector is valid; the mean minimises the norms);
+// sums[dim] receives the sum of all squares
+__global__ void bf16_column_sums_kernel(const float *__restrict__ P, size_t n, int dim, size_t ld, double *__restrict__ sums) {
+    const size_t r0 = (size_t)blockIdx.x * 1024;
+    const size_t r1 = r0 + 1024 < n ? r0 + 1024 : n;
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (size_t r = r0; r < r1; ++r) {
+            const float x = P[r * ld + k];
+            const double v = (fabsf(x) < 1.0e30f) ? (double)x : 0.0;
+            a += v;
+            b += v * v;
+        }
+        atomicAdd(&sums[k], a);
+        atomicAdd(&sums[dim], b);
+    }
+}
+hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_column_sums_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(128), 0, s, P, n, dim, ld, sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
+                                   uint32_t *bad, hipStream_t s) {
     const size_t rows = (n + kBP - 1) / kBP * kBP;
-    hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, n, dim, ld,
+    hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
                        bf16_ks_for(dim), static_cast<uint16_t *>(img), rows, bad);
     return hipGetLastError();
 }
 
-hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, int dim, size_t ld, void *B, double *qn,
-                                    uint32_t *qbad, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, nq, nq_pad,
+hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
+                                    void *B, double *qn, uint32_t *qbad, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
                        dim, ld, bf16_ks_for(dim), static_cast<uint16_t *>(B), qn, qbad);
     return hipGetLastError();
 }

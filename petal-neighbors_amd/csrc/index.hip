@@ -2,6 +2,7 @@
 // staging, engine selection and kernel orchestration.  gfx950 / ROCm only.
 // No CPU compute path exists here: without a GPU every compute entry point
 // returns PN_ERR_DEVICE.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -104,6 +105,8 @@ struct pn_index {
     float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
     bool mfma_ok = false;
     void *d_img = nullptr;   // f32, D <= 128: bf16 tile images of the corpus (bf16_filter.hip)
+    float *d_mu = nullptr;   // translation vector of the bf16 tier: the corpus mean per dimension, or zero
+    bool centered = false;   // d_mu != 0: translating shrinks the squared norms at least 16x
     bool bf16_ok = false;
     int bf16_level = 0;      // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
     int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
@@ -194,7 +197,36 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
             uint32_t *d_bad = nullptr;
             HIPCHK(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
             HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s));
-            HIPCHK(launch_bf16_pack_corpus((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, ix->d_img, d_bad, s));
+            {   // translation vector = per-dimension mean (f64 sums on the device, one division on the host)
+                double *d_sums = nullptr;
+                HIPCHK(hipMalloc((void **)&d_sums, (ix->dim + 1) * sizeof(double)));
+                HIPCHK(hipMemsetAsync(d_sums, 0, (ix->dim + 1) * sizeof(double), s));
+                HIPCHK(launch_bf16_column_sums((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, d_sums, s));
+                std::vector<double> h_sums(ix->dim + 1);
+                HIPCHK(hipMemcpyAsync(h_sums.data(), d_sums, (ix->dim + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                (void)hipFree(d_sums);
+                std::vector<float> h_mu(ix->dim);
+                double mu2 = 0.0;
+                for (size_t k = 0; k < ix->dim; ++k) {
+                    const double m = h_sums[k] / (double)ix->n;
+                    h_mu[k] = (m == m && std::fabs(m) < 1e30) ? (float)m : 0.0f;
+                    mu2 += (double)h_mu[k] * (double)h_mu[k];
+                }
+                // sum |p - mu|^2 = sum |p|^2 - n |mu|^2: translate only when that is a 16x reduction
+                const double s2 = h_sums[ix->dim], s2c = s2 - (double)ix->n * mu2;
+#ifdef PN_DIAG_NO_CENTER
+                ix->centered = false;
+#else
+                ix->centered = s2 > 0.0 && s2c < s2 / 16.0;
+#endif
+                if (!ix->centered) std::fill(h_mu.begin(), h_mu.end(), 0.0f);
+                HIPCHK(hipMalloc((void **)&ix->d_mu, ix->dim * sizeof(float)));
+                HIPCHK(hipMemcpyAsync(ix->d_mu, h_mu.data(), ix->dim * sizeof(float), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+            HIPCHK(launch_bf16_pack_corpus((const float *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, ix->d_img,
+                                           d_bad, s));
             uint32_t h_bad = 0;
             HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -329,6 +361,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     for (DevBuf *b : bufs) b->release();
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
+    if (ix->d_mu) (void)hipFree(ix->d_mu);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
     hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3, ix->ev4, ix->ev5};
     for (hipEvent_t e : evs)
@@ -528,8 +561,8 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
     return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
 
-// Plan of the bf16 tier for one call.  R ~ 2k rows have a bf16 bound below the k-th neighbour's distance on
-// benign data (the bound is loose by a few percent of the distance spread).  The proof needs every segment's
+// Plan of the bf16 tier for one call.  R ~ 1.5k rows have a bf16 bound below the k-th neighbour's distance on
+// benign data (the bound is loose by about a percent of the distance spread).  The proof needs every segment's
 // k'-th bound to clear that distance, i.e. k' above the number of those R rows that fall into one segment:
 //   level 0 (default): rows in arbitrary order -- a segment holds Poisson(R / segments) of them, k' is that mean
 //            plus five standard deviations + 3; a query tile served by fewer than 4 workgroups is split into row
@@ -559,7 +592,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     // workgroups set the kernel's time (C2: 512 workgroups = 12.8 per tile 4.34 ms, 480 = 12 per tile 3.62 ms)
     if (n_wg > q_tiles) n_wg = n_wg / q_tiles * q_tiles;
     p.n_wg = (int)n_wg;
-    const double R = kout < 32 ? 2.0 * (double)kout + 6.0 : 2.0 * (double)kout;
+    // rows whose bound lies below the k-th neighbour's distance: ~1.2 k on benign data once the vectors are
+    // translated by the corpus mean (measured: 11.8 for k = 10, 116 for k = 100); planned with a margin
+    const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
     size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
     if (per_tile < 1) per_tile = 1;
     auto kp_for = [&](int split) -> double {
@@ -795,7 +830,7 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     uint64_t *d_ncand = (uint64_t *)((char *)ix->w_bmisc.p + 8);
     uint32_t *d_nsel = (uint32_t *)((char *)ix->w_bmisc.p + 16);
     HIPCHK(hipMemsetAsync(ix->w_bmisc.p, 0, 64, s));
-    HIPCHK(launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
                                     (uint32_t *)ix->w_qbad.p, s));
     CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_keys.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
     HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -956,7 +991,7 @@ extern "C" int pn_query_nearest_f64(const pn_index *ix, const double *q, size_t 
 
 // diagnostic: the bf16 filter's lower bounds themselves (see the header)
 extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
-                                  size_t n_rows, float *bounds_out, double *qnorm_out) {
+                                  size_t n_rows, float *bounds_out, double *qnorm_out, float *mu_out) {
     if (!ix || !q || !bounds_out) return fail(PN_ERR_INVALID, "NULL argument");
     if (ix->elem_bytes != 4 || !ix->bf16_ok) return fail(PN_ERR_UNSUPPORTED, "index has no bf16 tier");
     if (q_cols != ix->dim) return fail(PN_ERR_INVALID, "queries must have the index's dimension");
@@ -983,12 +1018,13 @@ extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq,
         }
         float *Qp = (float *)ix->w_q.p;
         if (launch_pack_rows_f32(d_q, nq, ix->dim, q_cols, Qp, nq_pad, ix->ld, s) != hipSuccess ||
-            launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+            launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
                                      (uint32_t *)ix->w_qbad.p, s) != hipSuccess ||
             launch_bf16_bound(ix->d_img, ix->w_bq.p, n_rows, nq, (int)ix->dim, d_out, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess ||
             hipMemcpy(bounds_out, d_out, nq * n_rows * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-            (qnorm_out && hipMemcpy(qnorm_out, ix->w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) {
+            (qnorm_out && hipMemcpy(qnorm_out, ix->w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) ||
+            (mu_out && hipMemcpy(mu_out, ix->d_mu, ix->dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
             rc = fail(PN_ERR_DEVICE, "bf16 bounds failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
@@ -1097,7 +1133,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
     HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(launch_bf16_pack_queries(Qp, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
+    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
                                     (uint32_t *)ix->w_qbad.p, s));
     PNCHK(ix->w_gsel.ensure(nq * sizeof(uint32_t)));
     HIPCHK(launch_compact_flags((const uint32_t *)ix->w_qbad.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_misc + 1, s));

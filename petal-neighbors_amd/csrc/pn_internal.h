@@ -148,10 +148,13 @@ size_t bf16_image_bytes(size_t n, int dim);        // corpus tile images
 size_t bf16_query_bytes(size_t nq_pad, int dim);   // packed query rows
 int bf16_cap_for(int kp);                          // slots per (segment, query): 64 / 128 / 256
 int bf16_query_tile();                             // queries per workgroup (256)
-hipError_t launch_bf16_pack_corpus(const float *P, size_t n, int dim, size_t ld, void *img, uint32_t *bad,
-                                   hipStream_t s);
-hipError_t launch_bf16_pack_queries(const float *Q, size_t nq, size_t nq_pad, int dim, size_t ld, void *B, double *qn,
-                                    uint32_t *qbad, hipStream_t s);
+// mu: translation vector [dim]; sums: [dim + 1] per-dimension f64 sums of the corpus + the sum of all squares
+// (zeroed by the caller)
+hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
+hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
+                                   uint32_t *bad, hipStream_t s);
+hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
+                                    void *B, double *qn, uint32_t *qbad, hipStream_t s);
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);

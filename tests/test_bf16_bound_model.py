@@ -45,9 +45,11 @@ def bf16_up(f):  # f >= 0 float32 -> smallest bf16 >= f
     return (t.astype(np.uint32) << 16).view(np.float32)
 
 
-def corpus_columns(p):
-    ph = bf16_rne(p)
-    p64, ph64 = p.astype(np.float64), ph.astype(np.float64)
+def corpus_columns(p, mu=None):
+    """mu: translation vector (f32, per dimension); the tier works with p - mu (f64 subtraction)."""
+    p64 = p.astype(np.float64) - (0.0 if mu is None else mu.astype(np.float64)[None, :])
+    ph = bf16_rne(p64.astype(np.float32))
+    ph64 = ph.astype(np.float64)
     pn = (p64 * p64).sum(1)
     en = ((p64 - ph64) ** 2).sum(1)
     hn = (ph64 * ph64).sum(1)
@@ -60,9 +62,10 @@ def corpus_columns(p):
     return ph64, np.stack([h0, h1, h2], 1).astype(np.float64), bp.astype(np.float64), dp.astype(np.float64)
 
 
-def query_columns(q):
-    qh = bf16_rne(q)
-    q64, qh64 = q.astype(np.float64), qh.astype(np.float64)
+def query_columns(q, mu=None):
+    q64 = q.astype(np.float64) - (0.0 if mu is None else mu.astype(np.float64)[None, :])
+    qh = bf16_rne(q64.astype(np.float32))
+    qh64 = qh.astype(np.float64)
     s = (q64 * q64).sum(1)
     aq = bf16_up(f_up(np.sqrt((qh64 * qh64).sum(1)) * UP)).astype(np.float64)
     cq = bf16_up(f_up(np.sqrt(((q64 - qh64) ** 2).sum(1)) * UP)).astype(np.float64)
@@ -86,8 +89,9 @@ CASES = {
 def test_bound_holds_with_the_accumulation_allowance(name, dim):
     p = CASES[name](400, dim, 3)
     q = CASES[name](60, dim, 4)
-    ph, pieces, bp, dp = corpus_columns(p)
-    mq, aq, cq, qn = query_columns(q)
+    mu = p.astype(np.float64).mean(0).astype(np.float32)  # any translation is valid; the library uses the mean
+    ph, pieces, bp, dp = corpus_columns(p, mu)
+    mq, aq, cq, qn = query_columns(q, mu)
     dot = mq @ ph.T                                   # sum of (-2 q^_k) p^_k, exact enough in f64 (bf16 x bf16 terms)
     exact = pieces.sum(1)[None, :] + dot - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
     mags = pieces.sum(1)[None, :] + np.abs(mq) @ np.abs(ph).T + aq[:, None] * bp[None, :] + cq[:, None] * dp[None, :]
@@ -96,16 +100,17 @@ def test_bound_holds_with_the_accumulation_allowance(name, dim):
     slack = (d2 - qn[:, None]) - (exact + G * mags)
     # f64 evaluation noise of this model itself: ~1e-13 relative to the magnitudes
     assert (slack >= -1e-12 * mags).all(), f"{name}/D={dim}: margin violated by {slack.min()}"
-    # and |q|^2 handed to the proof is a lower bound
-    assert (qn <= (q64 * q64).sum(1)).all()
+    # and the constant handed to the proof is a lower bound of |q - mu|^2
+    assert (qn <= ((q64 - mu.astype(np.float64)) ** 2).sum(1)).all()
 
 
 def test_bound_is_tight_enough_to_be_useful_on_uniform_data():
     p = uniform((2000, 128), 5)
     q = uniform((50, 128), 6)
-    ph, pieces, bp, dp = corpus_columns(p)
-    mq, aq, cq, qn = query_columns(q)
+    mu = p.astype(np.float64).mean(0).astype(np.float32)
+    ph, pieces, bp, dp = corpus_columns(p, mu)
+    mq, aq, cq, qn = query_columns(q, mu)
     exact = pieces.sum(1)[None, :] + mq @ ph.T - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
     d2 = ((q.astype(np.float64)[:, None, :] - p.astype(np.float64)[None, :, :]) ** 2).sum(2)
     gap = d2 - (exact + qn[:, None])
-    assert gap.min() > 0 and gap.max() < 0.6          # squared distances are ~21 +- 2.2 here
+    assert gap.min() > 0 and gap.max() < 0.2          # squared distances are ~21 +- 2.2 here

@@ -25,8 +25,10 @@ def _bounds(pn, tree, qs, n_rows):
     n_rows = min(n_rows, tree.num_points())
     out = np.empty((nq, n_rows), dtype=np.float32)
     qn = np.empty(nq, dtype=np.float64)
-    check(_lib.lib().pn_bf16_bounds_f32(tree._h, qs.ctypes.data, nq, d, d, n_rows, out.ctypes.data, qn.ctypes.data))
-    return out, qn
+    mu = np.empty(d, dtype=np.float32)
+    check(_lib.lib().pn_bf16_bounds_f32(tree._h, qs.ctypes.data, nq, d, d, n_rows, out.ctypes.data, qn.ctypes.data,
+                                        mu.ctypes.data))
+    return out, qn, mu
 
 
 def _bf16_round(x):
@@ -57,16 +59,20 @@ def test_lower_bound_inequality(pn, name, dim):
     qs = CASES[name](nq, dim, 12)
     tree = pn.BallTree.euclidean(pts)
     assert tree.bf16_eligible
-    L, qn = _bounds(pn, tree, qs, 1024)
+    L, qn, mu = _bounds(pn, tree, qs, 1024)
     p64, q64 = pts[:1024].astype(np.float64), qs.astype(np.float64)
-    qq = (q64 * q64).sum(1)
+    qq = ((q64 - mu.astype(np.float64)) ** 2).sum(1)  # the tier works with vectors translated by the corpus mean
     assert np.all(qn <= qq) and np.all(qn >= qq * (1 - 1e-11))
+    # the translation is the corpus mean where that shrinks the squared norms at least 16x, else none
+    assert np.all(mu == 0) or np.allclose(mu, pts.astype(np.float64).mean(0), rtol=1e-5, atol=1e-30)
+    if name == "offset1000":
+        assert np.all(mu > 999)
     d2 = ((q64[:, None, :] - p64[None, :, :]) ** 2).sum(2)
     assert np.all(np.isfinite(L))
     gap = d2 - (L.astype(np.float64) + qn[:, None])
     assert gap.min() >= 0.0, f"{name}/D={dim}: bound exceeds the squared distance by {-gap.min()}"
     # the bound is useful on benign data: slack small against the spread of the squared distances
-    if name in ("uniform", "centered"):
+    if name in ("uniform", "centered", "offset1000"):
         assert gap.max() < 0.05 * d2.mean() + 1e-3
 
 
@@ -82,9 +88,9 @@ def test_matrix_core_accumulation_error_is_far_inside_the_allowance(pn, name, di
     pts = CASES[name](n, dim, 21)
     qs = CASES[name](nq, dim, 22)
     tree = pn.BallTree.euclidean(pts)
-    L, _ = _bounds(pn, tree, qs, n)
-    ph, pieces, bp, dp = corpus_columns(pts)
-    mq, aq, cq, _ = query_columns(qs)
+    L, _, mu = _bounds(pn, tree, qs, n)
+    ph, pieces, bp, dp = corpus_columns(pts, mu)
+    mq, aq, cq, _ = query_columns(qs, mu)
     exact = pieces.sum(1)[None, :] + mq @ ph.T - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
     mags = pieces.sum(1)[None, :] + np.abs(mq) @ np.abs(ph).T + aq[:, None] * bp[None, :] + cq[:, None] * dp[None, :]
     ratio = np.abs(L.astype(np.float64) - exact) / (G * mags)
@@ -130,10 +136,20 @@ def test_bf16_engine_is_the_auto_default_and_proves_uniform_data(pn, oracle_mod)
     assert 10 <= st["candidates"] / st["queries"] <= 2000, st
 
 
-def test_bf16_hostile_data_falls_back_and_stays_exact(pn, oracle_mod):
-    # large common offset: bf16 resolves nothing, every query must be handed to the f32 tiers
+def test_bf16_common_offset_is_served_by_the_tier(pn, oracle_mod):
+    # the tier works with vectors translated by the corpus mean: a large common offset costs nothing
     pts = uniform((8000, 64), 31) + np.float32(1000.0)
     qs = uniform((200, 64), 32) + np.float32(1000.0)
+    _check(pn, oracle_mod, pts, qs, 5, expect_fallback=False)
+
+
+def test_bf16_hostile_data_falls_back_and_stays_exact(pn, oracle_mod):
+    # tight clusters far apart: distances inside a cluster are far below bf16's resolution of the coordinates,
+    # bf16 resolves nothing and every query must be handed to the f32 tiers
+    rng = np.random.default_rng(9)
+    cen = (rng.random((8, 64), dtype=np.float32) * 100).astype(np.float32)
+    pts = (cen[rng.integers(0, 8, 8000)] + 0.01 * rng.standard_normal((8000, 64), dtype=np.float32)).astype(np.float32)
+    qs = (pts[rng.integers(0, 8000, 200)] + 0.001 * rng.standard_normal((200, 64), dtype=np.float32)).astype(np.float32)
     _check(pn, oracle_mod, pts, qs, 5, expect_fallback=True)
 
 
