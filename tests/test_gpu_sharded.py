@@ -43,6 +43,31 @@ def test_virtual_shards_merge_equals_single_index(pn, oracle_mod, shards, n, dim
     assert md.cpu().numpy().tobytes() == want_d.tobytes()
 
 
+@pytest.mark.parametrize("shards", [2, 8])
+def test_packed_query_buffers_merge_in_place(pn, oracle_mod, shards):
+    """The N > 1 fast path: every shard writes its top-k straight into the packed buffer an all-gather would send;
+    the concatenation of those buffers, unpacked as strided views, merges to the single-index answer."""
+    import torch
+    from petal_neighbors_amd.sharded import HipShardEngine, shard_bounds
+    n, dim, nq, k = 30000, 96, 333, 10
+    pts = uniform((n, dim), 91, np.float32)
+    qs = uniform((nq, dim), 92, np.float32)
+    qd = torch.from_numpy(qs).to("cuda:0")
+    bufs, eng = [], None
+    for r in range(shards):
+        lo, hi = shard_bounds(n, shards, r)
+        eng = HipShardEngine(0)
+        eng.build(pts[lo:hi], lo)
+        bufs.append(eng.query_packed(qd, k))
+    gathered = torch.cat(bufs)
+    g_idx, g_dst = eng.unpack(gathered, shards, nq, k)
+    mi, md = eng.merge(g_idx, g_dst, k)
+    torch.cuda.synchronize()
+    want_i, want_d = oracle_mod.brute_knn(pts, qs, k)
+    assert np.array_equal(mi.cpu().numpy().astype(np.uint64), want_i)
+    assert md.cpu().numpy().tobytes() == want_d.tobytes()
+
+
 def test_sharded_ball_tree_world_size_one(pn, oracle_mod):
     """ShardedBallTree without a process group = one shard: the bench.py code path."""
     import torch
