@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: auto engine (all tiers) vs the oracle's brute force, bit-exact.
-usage: fuzz_knn.py [n_cases] [seed]"""
+Test infrastructure (it uses the oracle): run by tests/test_gpu_fuzz.py, or by hand: python tests/fuzz_knn.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _ROOT)
-sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle  # noqa: E402
 import petal_neighbors_amd as pn  # noqa: E402
 from conftest import uniform  # noqa: E402

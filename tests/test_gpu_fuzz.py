@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_knn.py): the auto engine with all its tiers against the oracle's brute
+"""Randomised parity sweep (tests/fuzz_knn.py): the auto engine with all its tiers against the oracle's brute
 force, bit-exact, over random shapes and data families (uniform, centred, tight clusters, duplicates, sorted rows)."""
 import os
 import sys
@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
