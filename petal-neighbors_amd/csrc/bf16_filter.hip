@@ -40,7 +40,14 @@
 //    row pitch makes the ds_read_b128 fragment reads conflict-free), so staging is a linear LDS-DMA copy;
 //  * all per-query bookkeeping (threshold, fill count) lives in registers, appends are plain global
 //    stores into the (segment, query) buffers the select kernel reads -- no LDS atomics, no fences on
-//    the fast path, no flush copy.
+//    the fast path, no flush copy; the tile barrier waits for the LDS-DMA but not for those stores
+//    (bf_wait_dma);
+//  * the low four mantissa bits of a bound carry its accumulator register number, so the minimum of a
+//    lane's 16 bounds names its row (bf_chain<EMB>, bf_slow);
+//  * thresholds do not start at +inf: a scout pass over the run's first tiles seeds them -- within the
+//    launch from the run's own rows, or, with several segments per query, in a scout-only launch whose
+//    lists bf16_seed_kernel merges per query over all segments (host: bf16_plan in index.hip).
+// Measurements behind each of these, and what was tried and dropped: DESIGN.md section 4.0.
 #include "pn_internal.h"
 #include "topk_buffer.h"
 
