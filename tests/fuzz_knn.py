@@ -35,6 +35,14 @@ def run_case(c, rng):
     idx, dist = t.query_batch(qs, k)
     oi, od = oracle.brute_knn(pts, qs, k)
     ok = dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)
+    # radius queries through the same tiers: a radius just above / exactly at a stored distance (strict '<')
+    nr = min(nq, 8)
+    for r in (np.float32(od[0, int(rng.integers(0, od.shape[1]))]) * np.float32(1.000001), np.float32(od[0, -1])):
+        if not np.isfinite(r) or r <= 0:
+            continue
+        off, ids = t.query_radius_batch(qs[:nr], float(r))
+        for a in range(nr):
+            ok = ok and np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle.brute_radius(pts, qs[a], r))
     st = t.stats()
     print(f"case {c}: n={n} D={dim} nq={nq} k={k} {kind}: {'ok' if ok else 'MISMATCH'} fallback {st['fallback_queries']}/{st['queries']} cand/q {st['candidates']/max(st['queries'],1):.0f}", flush=True)
     return ok
