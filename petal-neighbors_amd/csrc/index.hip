@@ -1057,15 +1057,92 @@ template <> struct RadOps<double> {
 // query_radius through the MFMA filter (f32, D <= 128, finite positive r).  *done = false means the
 // caller must run the exact two-pass engine instead (a survivor list overflowed, or a query norm is not
 // finite): correctness never depends on this path being taken.
+// exact radius queries: count pass -> host exclusive scan -> fill pass (exact scan kernel); offs gets nq + 1
+// entries, *out a malloc'ed array of offs[nq] global row numbers, ascending per query
+template <typename T>
+static int radius_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, size_t dim_eff, T radius,
+                        std::vector<uint64_t> &offs, uint64_t **out, hipStream_t s) {
+    *out = nullptr;
+    uint32_t *d_counts = nullptr;
+    uint64_t *d_offs = nullptr, *d_fill = nullptr;
+    std::vector<uint32_t> h_counts;
+    std::vector<uint64_t> h_offs;
+    int rc = PN_OK;
+    do {
+        const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, 1, ix->opt_segments, 4096, 64);
+        const size_t cells = nq * (size_t)pl.nseg;
+        if (hipMalloc((void **)&d_counts, cells * 4) != hipSuccess || hipMalloc((void **)&d_offs, cells * 8) != hipSuccess) {
+            rc = fail(PN_ERR_NOMEM, "hipMalloc radius scratch failed");
+            break;
+        }
+        if (hipMemsetAsync(d_counts, 0, cells * 4, s) != hipSuccess ||
+            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
+                           pl.nseg, d_counts, nullptr, nullptr, ix->index_base, s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius count pass failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        h_counts.resize(cells);
+        h_offs.resize(cells);
+        if (hipMemcpyAsync(h_counts.data(), d_counts, cells * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius count copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        offs.assign(nq + 1, 0);
+        uint64_t run = 0;
+        for (size_t a = 0; a < nq; ++a) {
+            offs[a] = run;
+            for (int sg = 0; sg < pl.nseg; ++sg) {
+                h_offs[a * pl.nseg + sg] = run;
+                run += h_counts[a * pl.nseg + sg];
+            }
+        }
+        offs[nq] = run;
+        ix->stats.radius_results += run;
+        uint64_t *h_out = (uint64_t *)malloc((run ? run : 1) * sizeof(uint64_t));
+        if (!h_out) { rc = fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)run); break; }
+        *out = h_out;
+        if (run == 0) break;
+        if (hipMalloc((void **)&d_fill, run * 8) != hipSuccess) { rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed"); break; }
+        if (hipMemcpyAsync(d_offs, h_offs.data(), cells * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
+                           pl.nseg, d_counts, d_offs, d_fill, ix->index_base, s) != hipSuccess ||
+            hipMemcpyAsync(h_out, d_fill, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(PN_ERR_DEVICE, "radius fill pass failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    if (rc != PN_OK && *out) { free(*out); *out = nullptr; }
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_offs) (void)hipFree(d_offs);
+    if (d_fill) (void)hipFree(d_fill);
+    return rc;
+}
+
 // common tail of the filtered radius paths: kept rows per query (w_keys, ascending) -> CSR on the host
-static int radius_finish(const pn_index *ix, size_t nq, size_t kept_stride, uint32_t *d_misc, uint64_t *offsets,
-                         uint64_t **idx_out, bool *done, hipStream_t s) {
+static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
+                         const uint32_t *d_over, float radius, uint64_t *offsets, uint64_t **idx_out, bool *done,
+                         hipStream_t s) {
     uint32_t h_misc[2] = {0, 0};
     std::vector<uint32_t> h_n(nq);
     HIPCHK(hipMemcpyAsync(h_misc, d_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_n.data(), ix->w_flags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (h_misc[0] || h_misc[1]) return PN_OK;  // not done: exact engine
+    if (h_misc[1]) return PN_OK;                        // queries the filter cannot serve: next tier
+    if (h_misc[0] && (!d_over || h_misc[0] * 4 > nq)) return PN_OK;  // many overflowed lists: next tier for the call
+    // a few queries overflowed their survivor lists (dense neighbourhoods): only they are re-run exactly
+    std::vector<uint32_t> sel;
+    if (h_misc[0]) {
+        std::vector<uint32_t> h_over(nq);
+        HIPCHK(hipMemcpy(h_over.data(), d_over, nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t a = 0; a < nq; ++a)
+            if (h_over[a]) {
+                sel.push_back((uint32_t)a);
+                h_n[a] = 0;
+            }
+        HIPCHK(hipMemcpyAsync(ix->w_flags.p, h_n.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
     std::vector<uint64_t> h_off(nq + 1);
     uint64_t run = 0;
     for (size_t a = 0; a < nq; ++a) {
@@ -1094,9 +1171,56 @@ static int radius_finish(const pn_index *ix, size_t nq, size_t kept_stride, uint
             return rc;
         }
     }
+    ix->stats.radius_results += run;
+    if (!sel.empty()) {
+        const size_t nf = sel.size(), nf_pad = round_up(nf, (size_t)256);
+        std::vector<uint64_t> offs_x;
+        uint64_t *out_x = nullptr;
+        int rc = PN_OK;
+        if (ix->w_gsel.ensure(nf * sizeof(uint32_t)) != PN_OK || ix->w_gq.ensure(nf_pad * ix->ld * sizeof(float)) != PN_OK ||
+            hipMemsetAsync(ix->w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s) != hipSuccess ||
+            hipMemcpyAsync(ix->w_gsel.p, sel.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+            launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_gsel.p, (int)nf, (float *)ix->w_gq.p, s) != hipSuccess)
+            rc = fail(PN_ERR_DEVICE, "radius fallback staging failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc == PN_OK)
+            rc = radius_exact<float>(ix, (const float *)ix->w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
+        if (rc != PN_OK) {
+            free(h_out);
+            return rc;
+        }
+        // splice: overflowed queries take the exact lists, the others keep the filter's
+        const uint64_t total = run + offs_x[nf];
+        uint64_t *h_all = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+        if (!h_all) {
+            free(h_out);
+            free(out_x);
+            return fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)total);
+        }
+        uint64_t w = 0;
+        size_t j = 0;
+        for (size_t a = 0; a < nq; ++a) {
+            offsets[a] = w;
+            if (j < nf && sel[j] == a) {
+                const uint64_t c = offs_x[j + 1] - offs_x[j];
+                memcpy(h_all + w, out_x + offs_x[j], c * sizeof(uint64_t));
+                w += c;
+                ++j;
+            } else {
+                const uint64_t c = h_off[a + 1] - h_off[a];
+                memcpy(h_all + w, h_out + h_off[a], c * sizeof(uint64_t));
+                w += c;
+            }
+        }
+        offsets[nq] = w;
+        free(h_out);
+        free(out_x);
+        *idx_out = h_all;
+        ix->stats.fallback_queries += nf;
+        *done = true;
+        return PN_OK;
+    }
     memcpy(offsets, h_off.data(), (nq + 1) * sizeof(uint64_t));
     *idx_out = h_out;
-    ix->stats.radius_results += run;
     *done = true;
     return PN_OK;
 }
@@ -1130,6 +1254,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     PNCHK(ix->w_idx.ensure(cells * cap * 2 * sizeof(uint32_t)));      // (key, row) pairs
     PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));    // kept rows per query
     PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));             // kept counts
+    PNCHK(ix->w_bflags.ensure(nq_pad * sizeof(uint32_t)));            // per-query overflow flags
     uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
     HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -1143,8 +1268,10 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
                               (const uint32_t *)ix->w_seed.p, true, nullptr, s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2, s));
-    return radius_finish(ix, nq, kept_stride, d_misc, offsets, idx_out, done, s);
+                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2,
+                                   (uint32_t *)ix->w_bflags.p, s));
+    return radius_finish(ix, Qp, nq, kept_stride, d_misc, (const uint32_t *)ix->w_bflags.p, radius, offsets, idx_out, done,
+                         s);
 }
 
 static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
@@ -1183,8 +1310,8 @@ static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq
                                   nq_pad, tau_excl, cap, (uint32_t *)ix->w_cnt.p, (uint32_t *)ix->w_idx.p, (int)n_wg, s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 1, s));
-    return radius_finish(ix, nq, kept_stride, d_misc, offsets, idx_out, done, s);
+                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 1, nullptr, s));
+    return radius_finish(ix, Qp, nq, kept_stride, d_misc, nullptr, radius, offsets, idx_out, done, s);
 }
 
 template <typename T>
@@ -1205,11 +1332,7 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
     const size_t nq_pad = round_up(nq, (size_t)256);
     T *d_q = nullptr;
-    uint32_t *d_counts = nullptr;
-    uint64_t *d_offs = nullptr, *d_fill = nullptr;
     int rc = upload_rows<T>(q, nq, q_cols, q_stride, &d_q);
-    std::vector<uint32_t> h_counts;
-    std::vector<uint64_t> h_offs;
     do {
         if (rc != PN_OK) break;
         rc = ix->w_q.ensure(nq_pad * ix->ld * sizeof(T));
@@ -1235,54 +1358,13 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
                 ix->stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
             }
         }
-        const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, 1, ix->opt_segments, 4096, 64);
-        const size_t cells = nq * (size_t)pl.nseg;
-        if (hipMalloc((void **)&d_counts, cells * 4) != hipSuccess || hipMalloc((void **)&d_offs, cells * 8) != hipSuccess) {
-            rc = fail(PN_ERR_NOMEM, "hipMalloc radius scratch failed");
-            break;
-        }
-        if (hipMemsetAsync(d_counts, 0, cells * 4, s) != hipSuccess ||
-            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
-                           pl.nseg, d_counts, nullptr, nullptr, ix->index_base, s) != hipSuccess) {
-            rc = fail(PN_ERR_DEVICE, "radius count pass failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-        h_counts.resize(cells);
-        h_offs.resize(cells);
-        if (hipMemcpyAsync(h_counts.data(), d_counts, cells * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(PN_ERR_DEVICE, "radius count copy failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-        uint64_t run = 0;
-        for (size_t a = 0; a < nq; ++a) {
-            offsets[a] = run;
-            for (int sg = 0; sg < pl.nseg; ++sg) {
-                h_offs[a * pl.nseg + sg] = run;
-                run += h_counts[a * pl.nseg + sg];
-            }
-        }
-        offsets[nq] = run;
-        ix->stats.radius_results += run;
-        uint64_t *h_out = (uint64_t *)malloc((run ? run : 1) * sizeof(uint64_t));
-        if (!h_out) { rc = fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)run); break; }
-        *idx_out = h_out;
-        if (run == 0) break;
-        if (hipMalloc((void **)&d_fill, run * 8) != hipSuccess) { rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed"); break; }
-        if (hipMemcpyAsync(d_offs, h_offs.data(), cells * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
-            RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
-                           pl.nseg, d_counts, d_offs, d_fill, ix->index_base, s) != hipSuccess ||
-            hipMemcpyAsync(h_out, d_fill, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(PN_ERR_DEVICE, "radius fill pass failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
+        std::vector<uint64_t> offs;
+        rc = radius_exact<T>(ix, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s);
+        if (rc != PN_OK) break;
+        memcpy(offsets, offs.data(), (nq + 1) * sizeof(uint64_t));
     } while (0);
     if (rc != PN_OK && *idx_out) { free(*idx_out); *idx_out = nullptr; }
     if (d_q) (void)hipFree(d_q);
-    if (d_counts) (void)hipFree(d_counts);
-    if (d_offs) (void)hipFree(d_offs);
-    if (d_fill) (void)hipFree(d_fill);
     return rc;
 }
 

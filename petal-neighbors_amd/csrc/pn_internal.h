@@ -137,7 +137,8 @@ hipError_t launch_mfma_radius_f32(const float *P, const float *pnorm, size_t n, 
 // ridx_stride: element stride of the row lists (2 when they are the rows of (key, row) pairs)
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
-                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride, hipStream_t s);
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride,
+                                   uint32_t *over_q /* nullable: per-query overflow flags */, hipStream_t s);
 hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
                                 size_t kept_stride, uint64_t index_base, uint64_t *out, hipStream_t s);
 

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
                                                           uint32_t cap, const float *__restrict__ P, size_t ldp,
                                                           const float *__restrict__ Q, int dim, float r,
                                                           uint32_t *__restrict__ kept, uint32_t *__restrict__ nkept,
-                                                          uint32_t *__restrict__ overflow, int ridx_stride) {
+                                                          uint32_t *__restrict__ overflow, int ridx_stride,
+                                                          uint32_t *__restrict__ over_q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *srow = reinterpret_cast<uint32_t *>(smem);  // rows that pass the exact test
     __shared__ uint32_t n_pass;
@@ -497,16 +498,18 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
     if (lane == 0) {
         nkept[q] = n;
         if (over) atomicAdd(overflow, 1u);
+        if (over_q) over_q[q] = over ? 1u : 0u;
     }
 }
 
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
-                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride, hipStream_t s) {
+                                   uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride,
+                                   uint32_t *over_q, hipStream_t s) {
     const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q,
-                       dim, r, kept, nkept, overflow, ridx_stride);
+                       dim, r, kept, nkept, overflow, ridx_stride, over_q);
     return hipGetLastError();
 }
 

@@ -204,3 +204,25 @@ def test_bf16_ineligible_index(pn):
         tree.set_engine("bf16")
     wide = pn.BallTree.euclidean(uniform((5000, 200), 72))
     assert not wide.bf16_eligible
+
+
+def test_bf16_radius_mixed_density_falls_back_per_query(pn, oracle_mod):
+    """A few queries sit in a dense clump (thousands of rows within the radius: their survivor lists overflow),
+    the others have sparse neighbourhoods: only the dense ones are re-run exactly, the call stays on the tier."""
+    rng = np.random.default_rng(17)
+    base = uniform((40000, 32), 81)
+    clump = (base[123] + 0.01 * rng.standard_normal((3000, 32))).astype(np.float32)
+    pts = np.concatenate([base, clump]).astype(np.float32)
+    qs = np.concatenate([uniform((60, 32), 82), clump[:3] + np.float32(0.001)]).astype(np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    _, d = oracle_mod.brute_knn(pts, qs[:60], 4)
+    r = float(np.median(d[:, 3]))  # sparse queries: a handful of rows; clump queries: ~3000
+    off, idx = tree.query_radius_batch(qs, r)
+    sizes = []
+    for a in range(len(qs)):
+        want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+        assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), a
+        sizes.append(len(want))
+    assert max(sizes) > 2500 and sorted(sizes)[len(sizes) // 2] < 50
+    st = tree.stats()
+    assert 1 <= st["fallback_queries"] <= 5, st  # the clump queries only, not the whole call
