@@ -845,7 +845,10 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kBQ);
     if ((uint32_t)split > n_tiles) return hipErrorInvalidValue;
     const uint32_t spp = (uint32_t)mfma_v2_max_segments((size_t)q_tiles * split, n_wg);
-    if (cb.nseg < (int)(spp * split)) return hipErrorInvalidValue;
+    // a whole number of workgroups per query tile (and no row parts): every (segment, query) cell has exactly one
+    // writer and there are exactly n_wg / q_tiles segments
+    const bool aligned = split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0;
+    if (cb.nseg < (aligned ? n_wg / (int)q_tiles : (int)(spp * split))) return hipErrorInvalidValue;
     const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
     switch (bf16_ks_for(dim)) {
         case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);

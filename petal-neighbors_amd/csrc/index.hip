@@ -572,7 +572,7 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // A call that had to hand more than 1/16 of its queries to the next tier raises the index's level (sticky).
 struct Bf16Plan {
     int n_wg, split, nseg, kp, cap, scout_max;
-    bool ok;
+    bool ok, aligned;
     // shared scout (several segments per query): scout-only launch, merged seed of rank seed_rank, main launch
     bool shared_scout;
     int scout_tiles, seed_rank;
@@ -614,6 +614,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256;
     p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
     p.nseg = bf16_segments(q_tiles, p.n_wg, p.split);
+    // aligned partition: exactly n_wg / q_tiles segments, every cell written by exactly one workgroup
+    p.aligned = p.split == 1 && (size_t)p.n_wg >= q_tiles && (size_t)p.n_wg % q_tiles == 0;
+    if (p.aligned) p.nseg = p.n_wg / (int)q_tiles;
     // scouted rows should hold < 0.1 of the R relevant rows in expectation: tiles <= N / (10 R) / 64
     const double sm = (double)r_tiles / (10.0 * R);
     p.scout_max = sm > 64.0 ? 64 : (int)sm;
@@ -833,15 +836,18 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
                                     (uint32_t *)ix->w_qbad.p, s));
     CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_keys.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
-    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+    if (!plan.aligned) {  // cells without a writer must read "empty" (an aligned partition writes every cell)
+        HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+    }
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
     if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
         PNCHK(ix->w_lists.ensure(words * sizeof(float)));
         PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
+        if (!plan.aligned)
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
                                   nullptr, false, (float *)ix->w_lists.p, s));
         if (prof) HIPCHK(hipEventRecord(ix->ev4, s));  // the dominant kernel runs twice per call: both are timed
