@@ -44,6 +44,7 @@ CONFIGS = {
     "c4s": (1_000_000, 768, 10_000, 10),
     "c5s": (1_000_000, 96, 10_000, 10),
     "c5shard": (12_500_000, 96, 1_000_000, 10),  # one of the 8 row shards of configs[4]
+    "c2k1": (1_000_000, 128, 10_000, 1),         # query_nearest at the headline shape
     "c2s2": (500_000, 128, 10_000, 10),          # one shard of C2 at 2 / 4 / 8 GPUs
     "c2s4": (250_000, 128, 10_000, 10),
     "c2s8": (125_000, 128, 10_000, 10),
