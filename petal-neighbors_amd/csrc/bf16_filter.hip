@@ -100,19 +100,39 @@ __device__ __forceinline__ uint16_t bf_up(float x) {  // x >= 0: smallest bf16 >
     return (uint16_t)((u >> 16) + ((u & 0xFFFFu) ? 1u : 0u));
 }
 
+// ---- wide rows (D > 128): K-chunked images.  The contraction is cut into chunks of 4 MFMA steps (64 columns); one
+// (256-row tile, chunk) piece is a ready-made LDS image of 256 rows x 144 bytes (4 x 32 B of data + 16 B of padding:
+// nine 16-byte slots per row, an odd pitch, so the ds_read_b128 fragment reads are conflict-free).  Corpus and queries
+// use the same layout: [tile][chunk][256][72] bf16.
+constexpr int kWR = 256;                       // rows (or queries) per wide tile
+constexpr int kWPitch = 144;                   // bytes per (row, chunk)
+constexpr int kWPiece = kWR * kWPitch;         // 36 864 B = 36 LDS-DMA instructions of 1 KiB
+constexpr int kWStage = 2 * kWPiece;           // corpus piece + query piece
+__host__ __device__ inline int bf16_wide_chunks(int KS) { return (KS + 3) / 4; }
+__device__ __forceinline__ size_t bf_wide_at(size_t r, int k, int nkc) {  // bf16 index of column k of row r
+    return (((r / kWR) * (size_t)nkc + (size_t)(k >> 6)) * kWR + r % kWR) * (size_t)(kWPitch / 2) + (size_t)(k & 63);
+}
+
 // One thread per (padded) corpus row: bf16 row + the five extra columns, written into the tile image.
-// img: [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
+// narrow (D <= 128): img = [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
 __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
                                         size_t ld, int KS, uint16_t *__restrict__ img, size_t n_rows_img,
-                                        uint32_t *__restrict__ bad) {
+                                        uint32_t *__restrict__ bad, int wide) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows_img) return;
-    const int CP = 2 * KS + 1;
-    uint16_t *row = img + ((r / kBP) * (size_t)kBP + (r % kBP)) * (size_t)CP * 8;
+    const int CP = 2 * KS + 1, nkc = bf16_wide_chunks(KS);
     const int E = 16 * (KS - 1);
-    for (int k = 0; k < CP * 8; ++k) row[k] = 0;
+    auto at = [&](int k) -> uint16_t & { return wide ? img[bf_wide_at(r, k, nkc)] : img[r * (size_t)CP * 8 + k]; };
+    if (wide) {
+        for (int c = 0; c < nkc; ++c) {
+            uint16_t *piece = &img[bf_wide_at(r, 64 * c, nkc)];
+            for (int j = 0; j < kWPitch / 2; ++j) piece[j] = 0;
+        }
+    } else {
+        for (int k = 0; k < CP * 8; ++k) at(k) = 0;
+    }
     if (r >= n) {
-        row[E] = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+        at(E) = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
         return;
     }
     double pn = 0.0, en = 0.0, hn = 0.0;
@@ -125,7 +145,7 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
         const float cf = (float)c;
         const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);  // 2^-60
         const float xh = bf_f(hb);
-        row[k] = hb;
+        at(k) = hb;
         pn += c * c;
         const double e = c - (double)xh;
         en += e * e;
@@ -133,7 +153,7 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     }
     if (!finite || !(pn < 1.2676506002282294e30)) {  // 2^100
         atomicOr(bad, 1u);
-        row[E] = 0x7F80u;
+        at(E) = 0x7F80u;
         return;
     }
     // |p|^2 (1 - g), rounded down, in three truncated bf16 pieces
@@ -143,23 +163,30 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     const uint16_t h1 = bf_trunc(f_down(rem));
     rem -= (double)bf_f(h1);
     const uint16_t h2 = bf_trunc(f_down(rem));
-    row[E + 0] = h0;
-    row[E + 1] = h1;
-    row[E + 2] = h2;
+    at(E + 0) = h0;
+    at(E + 1) = h1;
+    at(E + 2) = h2;
     const double e_n = sqrt(en) * kUp, h_n = sqrt(hn) * kUp, p_n = sqrt(pn) * kUp;
-    row[E + 3] = bf_up(f_up((2.0 * e_n + 2.0 * kG * h_n) * (1.0 + 2.0 * kG)));
-    row[E + 4] = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
+    at(E + 3) = bf_up(f_up((2.0 * e_n + 2.0 * kG * h_n) * (1.0 + 2.0 * kG)));
+    at(E + 4) = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
 }
 
 // One thread per (padded) query: bf16 B row [K] (chunk c at 8c), |q|^2 rounded down (f64), flag.
 __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
                                          size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
-                                         double *__restrict__ qn, uint32_t *__restrict__ qbad) {
+                                         double *__restrict__ qn, uint32_t *__restrict__ qbad, int wide) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    const int K = 16 * KS, E = 16 * (KS - 1);
-    uint16_t *row = B + q * (size_t)K;
-    for (int k = 0; k < K; ++k) row[k] = 0;
+    const int K = 16 * KS, E = 16 * (KS - 1), nkc = bf16_wide_chunks(KS);
+    auto at = [&](int k) -> uint16_t & { return wide ? B[bf_wide_at(q, k, nkc)] : B[q * (size_t)K + k]; };
+    if (wide) {
+        for (int c = 0; c < nkc; ++c) {
+            uint16_t *piece = &B[bf_wide_at(q, 64 * c, nkc)];
+            for (int j = 0; j < kWPitch / 2; ++j) piece[j] = 0;
+        }
+    } else {
+        for (int k = 0; k < K; ++k) at(k) = 0;
+    }
     double s = 0.0, en = 0.0, hn = 0.0;
     bool finite = true;
     if (q < nq) {
@@ -171,7 +198,7 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
             const float cf = (float)c;
             const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const float xh = bf_f(hb);
-            row[k] = bf_rne(-2.0f * xh);  // exact: a power-of-two multiple of a bf16 value
+            at(k) = bf_rne(-2.0f * xh);  // exact: a power-of-two multiple of a bf16 value
             s += c * c;
             const double e = c - (double)xh;
             en += e * e;
@@ -179,14 +206,14 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
         }
     }
     const bool ok = finite && (s < 1.2676506002282294e30);
-    row[E + 0] = 0x3F80u;  // 1.0
-    row[E + 1] = 0x3F80u;
-    row[E + 2] = 0x3F80u;
+    at(E + 0) = 0x3F80u;  // 1.0
+    at(E + 1) = 0x3F80u;
+    at(E + 2) = 0x3F80u;
     if (ok) {
-        row[E + 3] = (uint16_t)(bf_up(f_up(sqrt(hn) * kUp)) | 0x8000u);  // -Aq
-        row[E + 4] = (uint16_t)(bf_up(f_up(sqrt(en) * kUp)) | 0x8000u);  // -Cq
+        at(E + 3) = (uint16_t)(bf_up(f_up(sqrt(hn) * kUp)) | 0x8000u);  // -Aq
+        at(E + 4) = (uint16_t)(bf_up(f_up(sqrt(en) * kUp)) | 0x8000u);  // -Cq
     } else {
-        for (int k = 0; k < dim; ++k) row[k] = 0;  // keep the arithmetic finite; the query is re-run exactly
+        for (int k = 0; k < dim; ++k) at(k) = 0;  // keep the arithmetic finite; the query is re-run exactly
     }
     qn[q] = ok ? s / kUp : 0.0;
     qbad[q] = ok ? 0u : 1u;
@@ -731,6 +758,224 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wide rows (128 < D <= 1024): the query operand no longer fits the register file, so the contraction is a
+// K-chunked tile product with BOTH operands streamed through LDS:
+//  * a workgroup is 8 waves and owns a 256-row x 256-query tile; wave (rh, qg) computes the 128 x 64 sub-tile of
+//    row half rh and query group qg in 4 x 2 accumulator blocks (128 VGPRs): per MFMA step 4 + 2 ds_read_b128 feed
+//    8 MFMAs (0.75 LDS reads per MFMA; the LDS sustains 2);
+//  * a stage is one chunk (4 steps = 64 columns) of both operands, 2 x 36 KiB, two stages; the eight waves issue the
+//    72 LDS-DMA pieces of the next stage (waves 0-3 the corpus piece, 4-7 the query piece) right behind the one
+//    barrier per chunk; the query chunks are re-streamed for every row tile from L2, where the XCD-aware block order
+//    below keeps them (and shares every corpus tile between the workgroups of an XCD);
+//  * after the last chunk of a row tile the eight blocks are tagged, reduced and filtered exactly as in the narrow
+//    kernel (bf_slow, bf_compact); the other wave of the SIMD keeps the matrix pipe busy meanwhile;
+//  * the two row halves of a workgroup are two SEGMENTS of the query (own buffers, own thresholds): the partition
+//    is (query tile, row range) per workgroup, per_tile workgroups per query tile, 2 per_tile segments per query;
+//  * thresholds start from a scout pass over the run's first tiles (own seed only).
+// ---------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restrict__ img, uint32_t n_tiles,
+                                                           const char *__restrict__ Bimg, uint32_t nkc, uint32_t kp,
+                                                           uint2 *__restrict__ cand, uint32_t *__restrict__ ccnt,
+                                                           uint32_t *__restrict__ ctau, size_t nq_pad,
+                                                           uint32_t per_tile, uint32_t scout_max) {
+    constexpr uint32_t CAP = 64u * M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    char *lds = reinterpret_cast<char *>(smem_raw);  // [2][kWStage]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jq = lane & 31, h = lane >> 5;
+    const int qg = wave & 3, rh = wave >> 2;
+
+    // Logical workgroup: hardware block b runs on XCD b % 8.  Giving each XCD a contiguous range of logical
+    // workgroups puts the per_tile row ranges of a few query tiles on one L2: those query tiles' chunks stay
+    // resident there and every corpus tile is fetched once per XCD for all the query tiles that walk it together.
+    uint32_t w = blockIdx.x;
+    const uint32_t W = gridDim.x;
+    if ((W & 7u) == 0) w = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
+    const uint32_t qt = w / per_tile, sg = w % per_tile;
+    const uint32_t rt0 = (uint32_t)((unsigned long long)sg * n_tiles / per_tile);
+    const uint32_t rt1 = (uint32_t)((unsigned long long)(sg + 1) * n_tiles / per_tile);
+    const size_t q0 = (size_t)qt * kWR + (size_t)qg * 64;                 // first query of this wave
+    const size_t cell0 = (size_t)(sg * 2 + rh) * nq_pad + q0;             // its (segment, query) cell
+
+    const float inf = __uint_as_float(0x7F800000u);
+    float tau0 = inf, tau1 = inf;
+    uint32_t cnt0 = 0, cnt1 = 0;
+    if (rt0 >= rt1) {  // more workgroups than row tiles: an empty segment
+        if (h == 0) {
+            ccnt[cell0 + jq] = 0;
+            ctau[cell0 + jq] = f2s(inf);
+            ccnt[cell0 + 32 + jq] = 0;
+            ctau[cell0 + 32 + jq] = f2s(inf);
+        }
+        return;
+    }
+
+    // LDS-DMA of one stage: 72 pieces of 1 KiB, nine per wave
+    const bool is_a = wave < 4;
+    const char *src0 = (is_a ? img : Bimg + (size_t)qt * nkc * kWPiece) + (size_t)(wave & 3) * 9216 + lane * 16;
+    char *dst0 = lds + (is_a ? 0 : kWPiece) + (wave & 3) * 9216;
+    auto issue = [&](uint32_t rt, uint32_t c, int stage) {
+        const char *src = src0 + (is_a ? ((size_t)rt * nkc + c) * (size_t)kWPiece : (size_t)c * kWPiece);
+        char *dst = dst0 + stage * kWStage;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_b *)(src + i * 1024), (lds_void_b *)(dst + i * 1024), 16, 0, 0);
+    };
+
+    int st = 0;       // stage that holds (or is receiving) the next chunk to contract
+    uint32_t ns = 0;  // vector-memory instructions issued since this wave's last LDS-DMA (bf_wait_dma)
+    f32x16 acc[4][2];
+    // contraction of row tile rt (its chunk 0 is already on its way into stage st); rt_end: end of the tile sequence
+    auto contract = [&](uint32_t rt, uint32_t rt_end) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[rb][0][i] = 0.0f;
+                acc[rb][1][i] = 0.0f;
+            }
+        for (uint32_t c = 0; c < nkc; ++c) {
+            // chunk barrier: every wave's share of this stage has landed and nobody still reads the other stage
+            bf_wait_dma(ns);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (c + 1 < nkc)
+                issue(rt, c + 1, st ^ 1);
+            else if (rt + 1 < rt_end)
+                issue(rt + 1, 0, st ^ 1);
+            ns = 0;
+            const char *A = lds + st * kWStage + (rh * 128 + jq) * kWPitch + h * 16;
+            const char *B = lds + st * kWStage + kWPiece + (qg * 64 + jq) * kWPitch + h * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) a[rb] = *reinterpret_cast<const bf16x8 *>(A + rb * 32 * kWPitch + s * 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) b[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + s * 32);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[1], acc[rb][1], 0, 0, 0);
+                }
+            }
+            st ^= 1;
+        }
+    };
+
+    // ---- scout pass (see bf16_filter_kernel): the first tiles contracted without buffers, thresholds seeded with
+    // the 5th smallest block minimum of the wave's rows
+    const uint32_t run_len = rt1 - rt0;
+    uint32_t t_scout = run_len / 16u < scout_max ? run_len / 16u : scout_max;
+#ifdef PN_DIAG_BF_NOSCOUT
+    t_scout = 0;
+#endif
+    if (t_scout) {
+        float s0[kScoutList], s1[kScoutList];
+#pragma unroll
+        for (int i = 0; i < kScoutList; ++i) { s0[i] = inf; s1[i] = inf; }
+        auto insert = [](float (&l)[kScoutList], float x) {
+            float c = x;
+#pragma unroll
+            for (int i = 0; i < kScoutList; ++i) {
+                const float lo = fminf(l[i], c);
+                c = fmaxf(l[i], c);
+                l[i] = lo;
+            }
+        };
+        __syncthreads();
+        issue(rt0, 0, st);
+        for (uint32_t rt = rt0; rt < rt0 + t_scout; ++rt) {
+            contract(rt, rt0 + t_scout);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                float m0 = acc[rb][0][0], m1 = acc[rb][1][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    m0 = fminf(m0, acc[rb][0][i]);
+                    m1 = fminf(m1, acc[rb][1][i]);
+                }
+                insert(s0, m0);
+                insert(s1, m1);
+            }
+        }
+        auto union5 = [](const float (&a)[kScoutList]) {
+            const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
+                        b4 = __shfl_xor(a[3], 32), b5 = __shfl_xor(a[4], 32);
+            const float x = fminf(fminf(a[4], b5), fminf(fmaxf(a[0], b4), fmaxf(a[3], b1)));
+            return fminf(x, fminf(fmaxf(a[1], b3), fmaxf(a[2], b2)));
+        };
+        tau0 = union5(s0);
+        tau1 = union5(s1);
+    }
+
+    uint2 *ce_blk0 = cand + cell0 * CAP;
+    uint2 *ce_blk1 = ce_blk0 + (size_t)32 * CAP;
+    uint2 *ceq0 = ce_blk0 + (size_t)jq * CAP, *ceq1 = ce_blk1 + (size_t)jq * CAP;
+
+    // ---- main pass
+    __syncthreads();
+    issue(rt0, 0, st);
+    ns = 0;
+    for (uint32_t rt = rt0; rt < rt1; ++rt) {
+        contract(rt, rt1);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[rb][0][i] = __uint_as_float((__float_as_uint(acc[rb][0][i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                acc[rb][1][i] = __uint_as_float((__float_as_uint(acc[rb][1][i]) & 0xFFFFFFF0u) | (uint32_t)i);
+            }
+            float m0 = acc[rb][0][0], m1 = acc[rb][1][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                m0 = fminf(m0, acc[rb][0][i]);
+                m1 = fminf(m1, acc[rb][1][i]);
+            }
+            const uint32_t row0 = rt * (uint32_t)kWR + (uint32_t)(rh * 128 + rb * 32);
+            if (__any(m0 < tau0))
+                bf_slow<M, false>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+            if (__any(m1 < tau1))
+                bf_slow<M, false>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+        }
+    }
+    // ---- end of run: at most kp candidates per query stay; publish count and threshold
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long need = __ballot(h == 0 && cnt0 > kp);
+    while (need) {
+        const int j = __builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, j);
+        uint32_t T, nn;
+        bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
+        if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
+    }
+    need = __ballot(h == 0 && cnt1 > kp);
+    while (need) {
+        const int j = __builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, j);
+        uint32_t T, nn;
+        bf_compact<M>(ce_blk1 + (size_t)j * CAP, cj, kp, lane, T, nn);
+        if (jq == j) { tau1 = s2f(T); cnt1 = nn; }
+    }
+#if defined(PN_DIAG_BF_NOSTORE) || defined(PN_DIAG_BF_NOSLOW)
+    cnt0 = 0;
+    cnt1 = 0;
+#endif
+    if (h == 0) {
+        ccnt[cell0 + jq] = cnt0;
+        ctau[cell0 + jq] = f2s(tau0);
+        ccnt[cell0 + 32 + jq] = cnt1;
+        ctau[cell0 + 32 + jq] = f2s(tau1);
+    }
+}
+
 #ifdef PN_DIAG_BF_COUNT
 extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
     unsigned long long z[8] = {0};
@@ -744,12 +989,21 @@ extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
 // host side
 // ---------------------------------------------------------------------------
 int bf16_ks_for(int dim) { return (dim + 15) / 16 + 1; }
-bool bf16_supported(int dim) { return dim >= 1 && dim <= 128; }
+// D <= 128: operand-stationary kernel (bf16_filter_kernel); 128 < D <= 1024: K-chunked kernel (bf16_wide_kernel).
+// The accumulation-error allowance g = 2^-13 was checked against chains of up to 65 MFMA steps (tests/test_gpu_bf16.py).
+bool bf16_supported(int dim) { return dim >= 1 && dim <= 1024; }
+bool bf16_is_wide(int dim) { return dim > 128; }
 size_t bf16_image_bytes(size_t n, int dim) {
+    if (bf16_is_wide(dim))
+        return (n + kWR - 1) / kWR * (size_t)bf16_wide_chunks(bf16_ks_for(dim)) * (size_t)kWPiece;
     const size_t n_tiles = (n + kBP - 1) / kBP;
     return n_tiles * (size_t)kBP * (size_t)(2 * bf16_ks_for(dim) + 1) * 16;
 }
-size_t bf16_query_bytes(size_t nq_pad, int dim) { return nq_pad * (size_t)bf16_ks_for(dim) * 32; }
+size_t bf16_query_bytes(size_t nq_pad, int dim) {
+    if (bf16_is_wide(dim))
+        return (nq_pad + kWR - 1) / kWR * (size_t)bf16_wide_chunks(bf16_ks_for(dim)) * (size_t)kWPiece;
+    return nq_pad * (size_t)bf16_ks_for(dim) * 32;
+}
 #ifdef PN_DIAG_BF_CAP
 int bf16_cap_for(int kp) { return kp + 32 <= PN_DIAG_BF_CAP ? PN_DIAG_BF_CAP : 256; }
 #else
@@ -783,16 +1037,17 @@ hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld,
 
 hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
                                    uint32_t *bad, hipStream_t s) {
-    const size_t rows = (n + kBP - 1) / kBP * kBP;
+    const bool wide = bf16_is_wide(dim);
+    const size_t rows = wide ? (n + kWR - 1) / kWR * kWR : (n + kBP - 1) / kBP * kBP;
     hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
-                       bf16_ks_for(dim), static_cast<uint16_t *>(img), rows, bad);
+                       bf16_ks_for(dim), static_cast<uint16_t *>(img), rows, bad, wide ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, hipStream_t s) {
     hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
-                       dim, ld, bf16_ks_for(dim), static_cast<uint16_t *>(B), qn, qbad);
+                       dim, ld, bf16_ks_for(dim), static_cast<uint16_t *>(B), qn, qbad, bf16_is_wide(dim) ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -847,7 +1102,7 @@ int bf16_segments(size_t q_tiles, int n_wg, int split) {
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                               hipStream_t s) {
-    if (!bf16_supported(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
+    if (!bf16_supported(dim) || bf16_is_wide(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
         cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0)
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kBP - 1) / kBP);
@@ -958,11 +1213,20 @@ __global__ __launch_bounds__(64) void bf16_bound_kernel(const char *__restrict__
     }
 }
 
+__global__ void bf16_wide_bound_kernel(const char *__restrict__ img, const char *__restrict__ Bimg, uint32_t KS,
+                                       uint32_t nkc, uint32_t n_rows, uint32_t nq, float *__restrict__ out);
 hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
                              hipStream_t s) {
     // img covers round_up(n_rows, 64) rows and B round_up(nq, 32) queries at least
     const dim3 grid((unsigned)((n_rows + 31) / 32), (unsigned)((nq + 31) / 32));
     const char *im = static_cast<const char *>(img);
+    if (bf16_is_wide(dim)) {  // img covers round_up(n_rows, 256) rows, B round_up(nq, 256) queries
+        if (!bf16_supported(dim)) return hipErrorInvalidValue;
+        const int KS = bf16_ks_for(dim);
+        hipLaunchKernelGGL(bf16_wide_bound_kernel, grid, dim3(64), 0, s, im, static_cast<const char *>(B), (uint32_t)KS,
+                           (uint32_t)bf16_wide_chunks(KS), (uint32_t)n_rows, (uint32_t)nq, out);
+        return hipGetLastError();
+    }
     const u32x4 *b = static_cast<const u32x4 *>(B);
 #define PN_BOUND_CASE(K)                                                                                       \
     case K:                                                                                                    \
@@ -975,6 +1239,68 @@ hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size
     }
 #undef PN_BOUND_CASE
     return hipGetLastError();
+}
+
+// ---- wide rows: launchers
+// cb: as for launch_bf16_filter, with cb.nseg == 2 * per_tile; the grid is (nq_pad / 256) * per_tile workgroups
+hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
+                                   int per_tile, int scout_max, hipStream_t s) {
+    if (!bf16_supported(dim) || !bf16_is_wide(dim) || cb.nq_pad % kWR || kp < 1 || kp + 32 > cb.cap ||
+        cb.idx_stride != 2 || cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || per_tile < 1 || scout_max < 0 ||
+        cb.nseg != 2 * per_tile)
+        return hipErrorInvalidValue;
+    const uint32_t n_tiles = (uint32_t)((n + kWR - 1) / kWR);
+    const uint32_t nkc = (uint32_t)bf16_wide_chunks(bf16_ks_for(dim));
+    const size_t grid = cb.nq_pad / kWR * (size_t)per_tile;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t sh = (size_t)2 * kWStage;
+#define PN_WIDE_CASE(MM)                                                                                            \
+    {                                                                                                               \
+        auto kern = bf16_wide_kernel<MM>;                                                                           \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                \
+            if (e != hipSuccess) return e;                                                                          \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sh, s, static_cast<const char *>(img), n_tiles,   \
+                           static_cast<const char *>(B), nkc, (uint32_t)kp, static_cast<uint2 *>(cb.keys), cb.cnt,  \
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)per_tile, (uint32_t)scout_max);    \
+    }
+    switch (cb.cap) {
+        case 64: PN_WIDE_CASE(1) break;
+        case 128: PN_WIDE_CASE(2) break;
+        case 256: PN_WIDE_CASE(4) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef PN_WIDE_CASE
+    return hipGetLastError();
+}
+
+// debug / test entry for wide rows: the same MFMA chain, step by step in the kernel's order
+__global__ __launch_bounds__(64) void bf16_wide_bound_kernel(const char *__restrict__ img, const char *__restrict__ Bimg,
+                                                             uint32_t KS, uint32_t nkc, uint32_t n_rows, uint32_t nq,
+                                                             float *__restrict__ out) {
+    const int lane = threadIdx.x, jq = lane & 31, h = lane >> 5;
+    const uint32_t rb = blockIdx.x, qb = blockIdx.y;
+    const size_t row = (size_t)rb * 32 + jq, q = (size_t)qb * 32 + jq;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (uint32_t ks = 0; ks < KS; ++ks) {
+        const size_t c = ks >> 2, so = (size_t)(ks & 3) * 32 + (size_t)h * 16;
+        const u32x4 av = *reinterpret_cast<const u32x4 *>(img + (((row / kWR) * nkc + c) * kWR + row % kWR) * kWPitch + so);
+        const u32x4 bv = *reinterpret_cast<const u32x4 *>(Bimg + (((q / kWR) * nkc + c) * kWR + q % kWR) * kWPitch + so);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                      acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const uint32_t qq = qb * 32 + jq;
+        if (i < n_rows && qq < nq) out[(size_t)qq * n_rows + i] = acc[r];
+    }
 }
 
 }  // namespace pn

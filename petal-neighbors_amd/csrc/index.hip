@@ -576,8 +576,61 @@ struct Bf16Plan {
     // shared scout (several segments per query): scout-only launch, merged seed of rank seed_rank, main launch
     bool shared_scout;
     int scout_tiles, seed_rank;
+    // wide rows (D > 128): per_tile workgroups per query tile, each a row range; 2 * per_tile segments per query
+    bool wide;
+    int per_tile;
 };
+// Wide rows: one workgroup per CU (144 KiB of LDS), a grid of q_tiles * per_tile workgroups, non-persistent.  per_tile
+// is chosen for the fullest last round of workgroups among the values that leave every run at least 8 row tiles.
+static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
+    Bf16Plan p{};
+    p.wide = true;
+    p.split = 1;
+    const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 255) / 256;
+    const size_t n_cu = (size_t)ix->n_cu;
+    size_t best = 1;
+    double best_eff = 0.0;
+    for (size_t c = 1; c <= 32; ++c) {
+        if (c > 1 && r_tiles / c < 8) break;
+        if (ix->opt_segments > 0 && 2 * c > (size_t)ix->opt_segments && c > 1) break;
+        const double rounds = (double)(q_tiles * c) / (double)n_cu;
+        double eff = rounds / std::ceil(rounds);
+        if (q_tiles * c <= n_cu) eff = rounds;  // a partial single round: more workgroups is simply better
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = c;
+        }
+    }
+    p.aligned = true;  // every (segment, query) cell is written by exactly one wave
+    const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
+    for (;; best = (best + 1) / 2) {
+        p.per_tile = (int)best;
+        p.n_wg = (int)(q_tiles * best);
+        p.nseg = 2 * p.per_tile;
+        double kp;
+        if (ix->filter_slots > 0)
+            kp = (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
+        else if (ix->bf16_level != 0)
+            kp = R + 6.0 * std::sqrt(R) + 4.0;
+        else {
+            const double per = R / (double)p.nseg;
+            kp = per + 5.0 * std::sqrt(per) + 3.0;
+            if (kp < 8.0) kp = 8.0;
+        }
+        p.kp = (int)std::ceil(kp);
+        p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256 && q_tiles * best <= 0x7FFFFFFFull;
+        p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
+        // the re-rank kernel gathers all cells of a query into 64 KiB of LDS (12 B per slot + the query row)
+        if (best == 1 || (size_t)p.nseg * (size_t)p.cap * 12 + (ix->dim + 8) * 4 <= 60 * 1024) break;
+    }
+    if ((size_t)p.nseg * (size_t)p.cap * 12 + (ix->dim + 8) * 4 > 64 * 1024) p.ok = false;
+    // a wave scouts 128 rows per tile; the scouted rows should hold < 0.1 of the R relevant rows in expectation
+    const double sm = (double)ix->n / (10.0 * R) / 128.0;
+    p.scout_max = sm > 32.0 ? 32 : (int)sm;
+    return p;
+}
 static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
+    if (bf16_is_wide((int)ix->dim)) return bf16_plan_wide(ix, nq_pad, kout);
     Bf16Plan p{};
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
     size_t n_wg = 2 * (size_t)ix->n_cu;
@@ -842,7 +895,10 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     }
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    if (plan.shared_scout) {
+    if (plan.wide) {
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
+                                       plan.scout_max, s));
+    } else if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
         PNCHK(ix->w_lists.ensure(words * sizeof(float)));
         PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
@@ -1350,7 +1406,7 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
         }
         if constexpr (sizeof(T) == 4) {
             const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
+            if (ix->bf16_ok && !bf16_is_wide((int)ix->dim) && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
                 (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;
                 rc = radius_bf16(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);

@@ -144,6 +144,7 @@ hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, con
 
 // ---- bf16_filter.hip: first-tier filter (bf16 MFMA lower bound of |q-p|^2 - |q|^2), D <= 128
 bool bf16_supported(int dim);
+bool bf16_is_wide(int dim);  // 128 < D: K-chunked kernel (launch_bf16_wide_filter), images in the chunked layout
 int bf16_ks_for(int dim);
 size_t bf16_image_bytes(size_t n, int dim);        // corpus tile images
 size_t bf16_query_bytes(size_t nq_pad, int dim);   // packed query rows
@@ -166,6 +167,10 @@ int bf16_segments(size_t q_tiles, int n_wg, int split);
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                               hipStream_t s);
+// wide rows: grid of (nq_pad / 256) * per_tile workgroups, cb.nseg == 2 * per_tile (a workgroup's two row halves are
+// two segments), every cell written; scout_max in 256-row tiles
+hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
+                                   int per_tile, int scout_max, hipStream_t s);
 int bf16_scout_list();
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);

@@ -85,7 +85,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("dim", [3, 16, 100, 128])
+@pytest.mark.parametrize("dim", [3, 16, 100, 128, 768])
 def test_bound_holds_with_the_accumulation_allowance(name, dim):
     p = CASES[name](400, dim, 3)
     q = CASES[name](60, dim, 4)

@@ -202,7 +202,7 @@ def test_bf16_ineligible_index(pn):
     assert not tree.bf16_eligible
     with pytest.raises(Exception):
         tree.set_engine("bf16")
-    wide = pn.BallTree.euclidean(uniform((5000, 200), 72))
+    wide = pn.BallTree.euclidean(uniform((5000, 1030), 72))  # rows beyond 1024 columns: no bf16 tier
     assert not wide.bf16_eligible
 
 
