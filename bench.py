@@ -199,7 +199,8 @@ def main():
         flops_per_launch = 2.0 * n_local * dim * nq * args.steps / launches
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
         if args.engine in ("auto", "bf16") and tree.bf16_eligible and n_local >= 4096 and dim >= 8:
-            engine_used, kernel_name, peak = "bf16", "bf16_filter_kernel", PEAK_BF16_MFMA_TFLOPS
+            engine_used, peak = "bf16", PEAK_BF16_MFMA_TFLOPS
+            kernel_name = "bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel"
         elif args.engine != "exact" and tree.mfma_eligible:
             engine_used, peak = "mfma", PEAK_F32_MFMA_TFLOPS
             kernel_name = ("mfma_filter_wide_kernel" if dim > 128 else

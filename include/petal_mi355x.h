@@ -64,7 +64,7 @@ enum {
                             one could not prove; tiers that cannot serve the index are skipped */
     PN_ENGINE_EXACT = 1, /* exact VALU scan only (always bit-exact by construction) */
     PN_ENGINE_MFMA = 2,  /* force the f32 MFMA filter path (f32 only); verified, falls back per query */
-    PN_ENGINE_BF16 = 3   /* force the bf16 MFMA filter as first tier (f32, D <= 128); verified, falls back per query */
+    PN_ENGINE_BF16 = 3   /* force the bf16 MFMA filter as first tier (f32, D <= 1024); verified, falls back per query */
 };
 
 enum {

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         // threshold that turns out too low merely sends the query to the next tier.
         const uint32_t run_len = rt1 - rt0;
 #ifdef PN_DIAG_BF_NOSCOUT
-        const uint32_t t_scout = 0;
+        uint32_t t_scout = 0;
 #else
         uint32_t t_scout = run_len / 16u < 64u ? run_len / 16u : 64u;
         if (t_scout > scout_max) t_scout = scout_max;  // host: keeps the scouted rows' share of true neighbours tiny
@@ -818,8 +818,11 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     const bool is_a = wave < 4;
     const char *src0 = (is_a ? img : Bimg + (size_t)qt * nkc * kWPiece) + (size_t)(wave & 3) * 9216 + lane * 16;
     char *dst0 = lds + (is_a ? 0 : kWPiece) + (wave & 3) * 9216;
+    auto src_of = [&](uint32_t rt, uint32_t c) {
+        return src0 + (is_a ? ((size_t)rt * nkc + c) * (size_t)kWPiece : (size_t)c * kWPiece);
+    };
     auto issue = [&](uint32_t rt, uint32_t c, int stage) {
-        const char *src = src0 + (is_a ? ((size_t)rt * nkc + c) * (size_t)kWPiece : (size_t)c * kWPiece);
+        const char *src = src_of(rt, c);
         char *dst = dst0 + stage * kWStage;
 #pragma unroll
         for (int i = 0; i < 9; ++i)
@@ -844,10 +847,12 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (c + 1 < nkc)
-                issue(rt, c + 1, st ^ 1);
-            else if (rt + 1 < rt_end)
-                issue(rt + 1, 0, st ^ 1);
+            // the nine LDS-DMA pieces of the next stage are issued one at a time between the first MFMA pairs: a
+            // burst of nine right behind the barrier keeps all eight waves in the memory pipeline's queue at once
+            // while the matrix pipe idles
+            const bool more = c + 1 < nkc || rt + 1 < rt_end;
+            const char *nsrc = c + 1 < nkc ? src_of(rt, c + 1) : src_of(rt + 1 < rt_end ? rt + 1 : rt, 0);
+            char *ndst = dst0 + (st ^ 1) * kWStage;
             ns = 0;
             const char *A = lds + st * kWStage + (rh * 128 + jq) * kWPitch + h * 16;
             const char *B = lds + st * kWStage + kWPiece + (qg * 64 + jq) * kWPitch + h * 16;
@@ -860,8 +865,23 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                 for (int qb = 0; qb < 2; ++qb) b[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + s * 32);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[1], acc[rb][1], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        acc[rb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[qb], acc[rb][qb], 0, 0, 0);
+                        const int m = (s * 4 + rb) * 2 + qb;  // MFMA number within the chunk
+                        const int piece = m / 3;
+                        if (m % 3 == 2 && piece < 9) {
+                            __builtin_amdgcn_sched_barrier(0);
+#ifndef PN_DIAG_BF_NODMA  // NODMA is timing-only: the tiles are never loaded
+                            if (more)
+#else
+                            if (false)
+#endif
+                                __builtin_amdgcn_global_load_lds((glb_void_b *)(nsrc + piece * 1024),
+                                                                 (lds_void_b *)(ndst + piece * 1024), 16, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
             }
             st ^= 1;
@@ -871,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     // ---- scout pass (see bf16_filter_kernel): the first tiles contracted without buffers, thresholds seeded with
     // the 5th smallest block minimum of the wave's rows
     const uint32_t run_len = rt1 - rt0;
-    uint32_t t_scout = run_len / 16u < scout_max ? run_len / 16u : scout_max;
+    uint32_t t_scout = run_len / 32u < scout_max ? run_len / 32u : scout_max;
 #ifdef PN_DIAG_BF_NOSCOUT
     t_scout = 0;
 #endif

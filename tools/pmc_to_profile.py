@@ -1,0 +1,32 @@
+"""Turn tools/pmc_summary.py output (gpurun_out/prof_<tag>/pmc_summary.json) into the profiles/*_pmc.json record that
+bench.py reads for roofline.traffic.  Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
+FETCH_SIZE (KB) under-reports 16-B-per-lane streaming reads by 2x -> x2; WRITE_SIZE (KB) exact.
+usage: pmc_to_profile.py <pmc_summary.json> <kernel> <config> <algorithmic bytes per launch> "<what>" > profiles/x.json"""
+import json
+import sys
+
+src, kernel, config, alg, what = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5]
+p = json.load(open(src))
+n_simd = 256 * 4
+xcd_cycles = p["GRBM_GUI_ACTIVE"] / 8.0
+out = {
+    "what": what,
+    "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"],
+    "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane streaming reads "
+                  "(MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact",
+    "hbm_bytes_per_launch": (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0,
+    "algorithmic_bytes_per_launch": alg,
+    "TCC_HIT_sum": p["TCC_HIT_sum"], "TCC_MISS_sum": p["TCC_MISS_sum"],
+    "l2_hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]),
+    "GRBM_GUI_ACTIVE_sum_over_8_XCD": p["GRBM_GUI_ACTIVE"],
+    "effective_clock_GHz": xcd_cycles / (p["_kernel_ms_mean"] * 1e6),
+    "SQ_VALU_MFMA_BUSY_CYCLES": p["SQ_VALU_MFMA_BUSY_CYCLES"],
+    "mfma_pipe_busy_frac": p["SQ_VALU_MFMA_BUSY_CYCLES"] / (xcd_cycles * n_simd),
+    "SQ_INSTS_MFMA": p["SQ_INSTS_MFMA"], "SQ_INSTS_VALU_incl_MFMA": p["SQ_INSTS_VALU"],
+    "SQ_INSTS_SALU": p["SQ_INSTS_SALU"], "SQ_INSTS_VMEM_WR": p["SQ_INSTS_VMEM_WR"],
+    "valu_per_mfma": (p["SQ_INSTS_VALU"] - p["SQ_INSTS_MFMA"]) / p["SQ_INSTS_MFMA"],
+    "SQ_WAVES": p["SQ_WAVES"], "SQ_WAVE_CYCLES_quad": p["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY_quad": p["SQ_WAIT_ANY"],
+    "SQ_WAIT_INST_ANY_quad": p["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY_quad": p["SQ_ACTIVE_INST_ANY"],
+    "kernel_ms_mean_under_pmc": p["_kernel_ms_mean"], "kernel": kernel, "config": config,
+}
+print(json.dumps(out, indent=1))
