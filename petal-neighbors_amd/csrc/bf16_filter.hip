@@ -774,12 +774,13 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 //    is (query tile, row range) per workgroup, per_tile workgroups per query tile, 2 per_tile segments per query;
 //  * thresholds start from a scout pass over the run's first tiles (own seed only).
 // ---------------------------------------------------------------------------
-template <int M>
+template <int M, bool RAD>
 __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                            const char *__restrict__ Bimg, uint32_t nkc, uint32_t kp,
                                                            uint2 *__restrict__ cand, uint32_t *__restrict__ ccnt,
                                                            uint32_t *__restrict__ ctau, size_t nq_pad,
-                                                           uint32_t per_tile, uint32_t scout_max) {
+                                                           uint32_t per_tile, uint32_t scout_max,
+                                                           const uint32_t *__restrict__ tau_init) {
     constexpr uint32_t CAP = 64u * M;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     char *lds = reinterpret_cast<char *>(smem_raw);  // [2][kWStage]
@@ -895,6 +896,11 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
 #ifdef PN_DIAG_BF_NOSCOUT
     t_scout = 0;
 #endif
+    if (tau_init) {  // thresholds given by the caller (radius queries: each query's fixed bound): no scouting
+        t_scout = 0;
+        tau0 = s2f(tau_init[q0 + jq]);
+        tau1 = s2f(tau_init[q0 + 32 + jq]);
+    }
     if (t_scout) {
         float s0[kScoutList], s1[kScoutList];
 #pragma unroll
@@ -959,14 +965,14 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             }
             const uint32_t row0 = rt * (uint32_t)kWR + (uint32_t)(rh * 128 + rb * 32);
             if (__any(m0 < tau0))
-                bf_slow<M, false>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                bf_slow<M, RAD>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
             if (__any(m1 < tau1))
-                bf_slow<M, false>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                bf_slow<M, RAD>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
         }
     }
     // ---- end of run: at most kp candidates per query stay; publish count and threshold
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long need = __ballot(h == 0 && cnt0 > kp);
+    unsigned long long need = RAD ? 0ull : __ballot(h == 0 && cnt0 > kp);
     while (need) {
         const int j = __builtin_ctzll(need);
         need &= need - 1;
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
         bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
         if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
     }
-    need = __ballot(h == 0 && cnt1 > kp);
+    need = RAD ? 0ull : __ballot(h == 0 && cnt1 > kp);
     while (need) {
         const int j = __builtin_ctzll(need);
         need &= need - 1;
@@ -1264,19 +1270,19 @@ hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size
 // ---- wide rows: launchers
 // cb: as for launch_bf16_filter, with cb.nseg == 2 * per_tile; the grid is (nq_pad / 256) * per_tile workgroups
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, hipStream_t s) {
+                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s) {
     if (!bf16_supported(dim) || !bf16_is_wide(dim) || cb.nq_pad % kWR || kp < 1 || kp + 32 > cb.cap ||
         cb.idx_stride != 2 || cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || per_tile < 1 || scout_max < 0 ||
-        cb.nseg != 2 * per_tile)
+        cb.nseg != 2 * per_tile || (radius && (cb.cap != 256 || !tau_init)))
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kWR - 1) / kWR);
     const uint32_t nkc = (uint32_t)bf16_wide_chunks(bf16_ks_for(dim));
     const size_t grid = cb.nq_pad / kWR * (size_t)per_tile;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t sh = (size_t)2 * kWStage;
-#define PN_WIDE_CASE(MM)                                                                                            \
+#define PN_WIDE_CASE(MM, RR)                                                                                        \
     {                                                                                                               \
-        auto kern = bf16_wide_kernel<MM>;                                                                           \
+        auto kern = bf16_wide_kernel<MM, RR>;                                                                       \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                \
@@ -1286,13 +1292,18 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
         }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sh, s, static_cast<const char *>(img), n_tiles,   \
                            static_cast<const char *>(B), nkc, (uint32_t)kp, static_cast<uint2 *>(cb.keys), cb.cnt,  \
-                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)per_tile, (uint32_t)scout_max);    \
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)per_tile, (uint32_t)scout_max,    \
+                           tau_init);                                                                               \
     }
-    switch (cb.cap) {
-        case 64: PN_WIDE_CASE(1) break;
-        case 128: PN_WIDE_CASE(2) break;
-        case 256: PN_WIDE_CASE(4) break;
-        default: return hipErrorInvalidValue;
+    if (radius) {
+        PN_WIDE_CASE(4, true)
+    } else {
+        switch (cb.cap) {
+            case 64: PN_WIDE_CASE(1, false) break;
+            case 128: PN_WIDE_CASE(2, false) break;
+            case 256: PN_WIDE_CASE(4, false) break;
+            default: return hipErrorInvalidValue;
+        }
     }
 #undef PN_WIDE_CASE
     return hipGetLastError();

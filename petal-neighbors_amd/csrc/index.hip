@@ -904,7 +904,7 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
     if (plan.wide) {
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
-                                       plan.scout_max, s));
+                                       plan.scout_max, nullptr, false, s));
     } else if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
         PNCHK(ix->w_lists.ensure(words * sizeof(float)));
@@ -1306,7 +1306,13 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     if (by_work < cap_wg) cap_wg = by_work;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
-    const int nseg = bf16_segments(q_tiles, (int)n_wg, 1);
+    const bool wide = bf16_is_wide((int)ix->dim);
+    int per_tile = 1;
+    if (wide) {  // the k-NN plan's partition, at most 16 row ranges (32 segments) per query tile
+        per_tile = bf16_plan_wide(ix, nq_pad, 1).per_tile;
+        if (per_tile > 16) per_tile = 16;
+    }
+    const int nseg = wide ? 2 * per_tile : bf16_segments(q_tiles, (int)n_wg, 1);
     const size_t cells = (size_t)nseg * nq_pad;
     const size_t kept_stride = (size_t)nseg * cap;
     // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24): every row whose reference distance is < r has a squared distance
@@ -1333,8 +1339,12 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     HIPCHK(launch_compact_flags((const uint32_t *)ix->w_qbad.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_misc + 1, s));
     HIPCHK(launch_bf16_radius_tau((const double *)ix->w_qn.p, nq_pad, t, (uint32_t *)ix->w_seed.p, s));
     CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
-    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
-                              (const uint32_t *)ix->w_seed.p, true, nullptr, s));
+    if (wide)
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, per_tile, 0,
+                                       (const uint32_t *)ix->w_seed.p, true, s));
+    else
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
+                                  (const uint32_t *)ix->w_seed.p, true, nullptr, s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                    (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2,
@@ -1413,7 +1423,7 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
         }
         if constexpr (sizeof(T) == 4) {
             const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-            if (ix->bf16_ok && !bf16_is_wide((int)ix->dim) && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
+            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
                 (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;
                 rc = radius_bf16(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);

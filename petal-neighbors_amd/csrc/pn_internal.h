@@ -169,8 +169,9 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
                               hipStream_t s);
 // wide rows: grid of (nq_pad / 256) * per_tile workgroups, cb.nseg == 2 * per_tile (a workgroup's two row halves are
 // two segments), every cell written; scout_max in 256-row tiles
+// tau_init (nullable): starting thresholds per query; radius: fixed thresholds, overflow instead of compaction (cap 256)
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, hipStream_t s);
+                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s);
 int bf16_scout_list();
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);

@@ -112,3 +112,29 @@ def test_rows_beyond_1024_columns_have_no_bf16_tier(pn, oracle_mod):
     idx, dist = tree.query_batch(qs, 3)
     oidx, odist = oracle_mod.brute_knn(pts, qs, 3)
     assert dist.tobytes() == odist.tobytes() and np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("engine", ["bf16", "auto"])
+def test_wide_query_radius(pn, oracle_mod, engine):
+    """query_radius on wide rows through the bf16 filter's fixed-threshold mode: sparse results stay on it, dense
+    results overflow the survivor lists and are re-run exactly; boundary radii keep the strict '<'."""
+    for n, dim in ((12000, 256), (7000, 768), (5000, 130)):
+        pts = uniform((n, dim), 91 + dim, np.float32)
+        qs = np.concatenate([pts[:10], uniform((23, dim), 92 + dim, np.float32)])
+        tree = pn.BallTree.euclidean(pts)
+        tree.set_engine(engine)
+        _, d = oracle_mod.brute_knn(pts, qs, 40)
+        radii = [float(np.median(d[:, 3])), float(d[12, 5]), float(d[:, 30].max()) * 1.01, float(d.max()) * 1.2, 1e-6,
+                 0.0, -1.0, float("inf"), float("nan")]
+        for r in radii:
+            off, idx = tree.query_radius_batch(qs, r)
+            assert off[0] == 0 and off[-1] == len(idx)
+            for a in range(len(qs)):
+                want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+                assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), (n, dim, r, a, engine)
+    pts = uniform((9000, 512), 97, np.float32)
+    q = uniform((512,), 98, np.float32)
+    tree = pn.BallTree.euclidean(pts).set_engine(engine)
+    i5, d5 = tree.query(q, 5)
+    got = tree.query_radius(q, float(d5[4]))
+    assert list(got) == sorted(int(i) for i in i5[:4])
