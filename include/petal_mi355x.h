@@ -179,6 +179,18 @@ double pn_rdistance_to_distance_f64(double d);
 float pn_distance_to_rdistance_f32(float d);
 double pn_distance_to_rdistance_f64(double d);
 
+/* ---- Metric<A> for Cosine (src/distance.rs:76-122): distance = 1 - dot / (|a| |b|) with the reference's three
+ * sequential sums (the dot product over the shorter length, each norm over its own vector); rdistance and both
+ * conversions are the identity there.  pn_pairwise_cosine_*: distance::pairwise(x, &Cosine) on the GPU, same
+ * contract as pn_pairwise_*.  BallTree::new(points, Cosine) is NOT offered: cosine distance is not a metric, the
+ * reference's pruned walk returns walk-dependent answers under it, and this engine replaces that walk. */
+float pn_cosine_f32(const float *a, size_t len_a, const float *b, size_t len_b);
+double pn_cosine_f64(const double *a, size_t len_a, const double *b, size_t len_b);
+int pn_pairwise_cosine_f32(const float *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,
+                           float *out);
+int pn_pairwise_cosine_f64(const double *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,
+                           double *out);
+
 /* ---- row-sharded corpora: merge `n_parts` per-shard results
  * (each nq x k_part, already carrying global indices via PN_OPT_INDEX_BASE and
  * sorted by (distance, index)) into the global top k_out.  Device pointers.

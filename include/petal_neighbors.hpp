@@ -45,6 +45,29 @@ struct Euclidean {
     float distance_to_rdistance(float d) const { return pn_distance_to_rdistance_f32(d); }
     double distance_to_rdistance(double d) const { return pn_distance_to_rdistance_f64(d); }
 };
+// Cosine (src/distance.rs:76-122): 1 - dot / (|a| |b|); rdistance and the conversions are the identity
+struct Cosine {
+    bool operator==(const Cosine &) const { return true; }
+    float distance(const float *a, const float *b, size_t len) const { return pn_cosine_f32(a, len, b, len); }
+    double distance(const double *a, const double *b, size_t len) const { return pn_cosine_f64(a, len, b, len); }
+    float rdistance(const float *a, const float *b, size_t len) const { return distance(a, b, len); }
+    double rdistance(const double *a, const double *b, size_t len) const { return distance(a, b, len); }
+    float rdistance_to_distance(float d) const { return d; }
+    double rdistance_to_distance(double d) const { return d; }
+    float distance_to_rdistance(float d) const { return d; }
+    double distance_to_rdistance(double d) const { return d; }
+};
+// pairwise(x, &Cosine)
+inline std::vector<float> pairwise(const float *x, size_t n, size_t d, const Cosine &, int device = 0) {
+    std::vector<float> out(n * n);
+    check(pn_pairwise_cosine_f32(x, n, d, (ptrdiff_t)d, device, out.data()));
+    return out;
+}
+inline std::vector<double> pairwise(const double *x, size_t n, size_t d, const Cosine &, int device = 0) {
+    std::vector<double> out(n * n);
+    check(pn_pairwise_cosine_f64(x, n, d, (ptrdiff_t)d, device, out.data()));
+    return out;
+}
 // pairwise (src/distance.rs:58-74): n x n row-major
 inline std::vector<float> pairwise(const float *x, size_t n, size_t d, int device = 0) {
     std::vector<float> out(n * n);

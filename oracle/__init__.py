@@ -60,6 +60,8 @@ def _declare(L):
         f = getattr(L, f"oracle_rdistance_to_distance_{sfx}"); f.restype = ct; f.argtypes = [ct]
         f = getattr(L, f"oracle_distance_to_rdistance_{sfx}"); f.restype = ct; f.argtypes = [ct]
         f = getattr(L, f"oracle_pairwise_{sfx}"); f.restype = None; f.argtypes = [P, _SZ, _SZ, _SZ, P]
+        f = getattr(L, f"oracle_cosine_{sfx}"); f.restype = ct; f.argtypes = [P, _SZ, P, _SZ]
+        f = getattr(L, f"oracle_pairwise_cosine_{sfx}"); f.restype = None; f.argtypes = [P, _SZ, _SZ, _SZ, P]
         f = getattr(L, f"oracle_brute_knn_{sfx}"); f.restype = _SZ
         f.argtypes = [P, _SZ, _SZ, _SZ, P, _SZ, _SZ, _SZ, _U64P, P]
         f = getattr(L, f"oracle_brute_radius_{sfx}"); f.restype = _SZ
@@ -134,6 +136,23 @@ def reuclidean(a, b):
     s, ct = _sfx(a.dtype)
     n = min(a.shape[0], b.shape[0])
     return a.dtype.type(getattr(lib(), f"oracle_reuclidean_{s}")(_ptr(a, ct), _ptr(b, ct), n))
+
+
+def cosine(a, b):
+    """Cosine::distance, src/distance.rs:85-107 (rdistance and both conversions are the identity, :109-121)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b, dtype=a.dtype)
+    s, ct = _sfx(a.dtype)
+    return a.dtype.type(getattr(lib(), f"oracle_cosine_{s}")(_ptr(a, ct), a.shape[0], _ptr(b, ct), b.shape[0]))
+
+
+def pairwise_cosine(x):
+    """src/distance.rs:58-74 with the Cosine metric"""
+    x, ld = _rows(np.atleast_2d(x))
+    s, ct = _sfx(x.dtype)
+    n, d = x.shape
+    out = np.empty((n, n), dtype=x.dtype)
+    getattr(lib(), f"oracle_pairwise_cosine_{s}")(_ptr(x, ct), n, d, ld, _ptr(out, ct))
+    return out
 
 
 def rdistance_to_distance(d, dtype=np.float64):

@@ -48,6 +48,33 @@ T FN(oracle_rdistance_to_distance)(T d) { return SQRT(d); }
 /* src/distance.rs:52-54  d.powi(2) == d*d (one rounding) */
 T FN(oracle_distance_to_rdistance)(T d) { return d * d; }
 
+/* ---- src/distance.rs:85-107  Cosine::distance = 1 - dot / (sqrt(sum x1^2) * sqrt(sum x2^2)); each of the
+ * three sums is a sequential iterator sum in index order (products and additions rounded separately).
+ * rdistance and both conversions are the identity (src/distance.rs:109-121). ---- */
+T FN(oracle_cosine)(const T *x1, size_t len1, const T *x2, size_t len2)
+{
+    /* the dot product zips the two vectors (shorter length); each norm zips a vector with itself (its own length) */
+    const size_t lz = len1 < len2 ? len1 : len2;
+    T dot = (T)0, n1 = (T)0, n2 = (T)0;
+    for (size_t i = 0; i < lz; ++i) dot += x1[i] * x2[i];
+    for (size_t i = 0; i < len1; ++i) n1 += x1[i] * x1[i];
+    for (size_t i = 0; i < len2; ++i) n2 += x2[i] * x2[i];
+    return (T)1 - dot / (SQRT(n1) * SQRT(n2));
+}
+
+/* src/distance.rs:58-74 with metric = Cosine */
+void FN(oracle_pairwise_cosine)(const T *x, size_t n, size_t dim, size_t ld, T *out)
+{
+    for (size_t i = 0; i < n * n; ++i) out[i] = (T)0;
+    if (n < 2) return;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j) {
+            T d = FN(oracle_cosine)(x + i * ld, dim, x + j * ld, dim);
+            out[i * n + j] = d;
+            out[j * n + i] = d;
+        }
+}
+
 /* ---- src/distance.rs:58-74  pairwise: zero matrix, i<j filled + mirrored;
  * n < 2 -> zeros. ---- */
 void FN(oracle_pairwise)(const T *x, size_t n, size_t dim, size_t ld, T *out)

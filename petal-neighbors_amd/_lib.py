@@ -58,6 +58,10 @@ SIGNATURES = {
     "pn_free": (None, [_vp]),
     "pn_pairwise_f32": (_i, [_vp, _sz, _sz, _ssz, _i, _vp]),
     "pn_pairwise_f64": (_i, [_vp, _sz, _sz, _ssz, _i, _vp]),
+    "pn_pairwise_cosine_f32": (_i, [_vp, _sz, _sz, _ssz, _i, _vp]),
+    "pn_pairwise_cosine_f64": (_i, [_vp, _sz, _sz, _ssz, _i, _vp]),
+    "pn_cosine_f32": (C.c_float, [_vp, _sz, _vp, _sz]),
+    "pn_cosine_f64": (C.c_double, [_vp, _sz, _vp, _sz]),
     "pn_euclidean_f32": (C.c_float, [_vp, _vp, _sz]),
     "pn_euclidean_f64": (C.c_double, [_vp, _vp, _sz]),
     "pn_reuclidean_f32": (C.c_float, [_vp, _vp, _sz]),

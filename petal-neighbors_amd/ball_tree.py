@@ -55,7 +55,9 @@ class BallTree:
         Raises ``ArrayError.Empty`` for zero rows and ``ArrayError.NotContiguous`` when the
         inner stride is not 1 (only the inner stride is checked, as at :47)."""
         if not isinstance(metric, Euclidean):
-            raise NotImplementedError("only distance.Euclidean is on the MI355X path")
+            raise NotImplementedError("only distance.Euclidean is on the MI355X path (distance.Cosine is served as a "
+                                      "pair metric and by distance.pairwise: it is not a metric, so the reference's "
+                                      "pruned walk under it has no walk-independent answer to reproduce)")
         a = _float_array(points)
         if a.ndim != 2:
             raise ValueError("points must be a 2-D array (Ix2)")

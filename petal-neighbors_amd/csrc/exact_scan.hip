@@ -402,4 +402,56 @@ hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t 
     return launch_exact_pairwise<double>(X, n, dim, ld, out, s);
 }
 
+// ---------------------------------------------------------------------------
+// distance::pairwise(x, &Cosine) (src/distance.rs:58-74, 85-107): out[i][j] = 1 - dot(x_i, x_j) / (|x_i| |x_j|),
+// zero diagonal.  Every sum is the reference's sequential fold in index order (no FMA: -ffp-contract=off); products
+// and the denominator commute exactly, so both triangles equal the reference's mirrored fill.  Small matrices by
+// nature (n^2 outputs): one thread per pair, norms first.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void cosine_norms_kernel(const T *__restrict__ X, size_t n, int dim, size_t ld, T *__restrict__ norms) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T *r = X + i * ld;
+    T s = (T)0;
+    for (int k = 0; k < dim; ++k) {
+        const T pr = r[k] * r[k];
+        s = s + pr;
+    }
+    norms[i] = pn_sqrt(s);
+}
+template <typename T>
+__global__ void cosine_pairwise_kernel(const T *__restrict__ X, size_t n, int dim, size_t ld,
+                                       const T *__restrict__ norms, T *__restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    if (i == j) {
+        out[i * n + j] = (T)0;
+        return;
+    }
+    const T *a = X + i * ld, *b = X + j * ld;
+    T dot = (T)0;
+    for (int k = 0; k < dim; ++k) {
+        const T pr = a[k] * b[k];
+        dot = dot + pr;
+    }
+    const T den = norms[i] * norms[j];
+    out[i * n + j] = (T)1 - dot / den;
+}
+template <typename T>
+static hipError_t launch_cosine_pairwise(const T *X, size_t n, int dim, size_t ld, T *norms, T *out, hipStream_t s) {
+    hipLaunchKernelGGL((cosine_norms_kernel<T>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, X, n, dim, ld, norms);
+    hipLaunchKernelGGL((cosine_pairwise_kernel<T>), dim3((unsigned)((n + 127) / 128), (unsigned)n), dim3(128), 0, s, X, n,
+                       dim, ld, norms, out);
+    return hipGetLastError();
+}
+hipError_t launch_cosine_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *norms, float *out,
+                                      hipStream_t s) {
+    return launch_cosine_pairwise<float>(X, n, dim, ld, norms, out, s);
+}
+hipError_t launch_cosine_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *norms, double *out,
+                                      hipStream_t s) {
+    return launch_cosine_pairwise<double>(X, n, dim, ld, norms, out, s);
+}
+
 }  // namespace pn

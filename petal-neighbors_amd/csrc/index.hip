@@ -1461,7 +1461,8 @@ extern "C" void pn_free(void *p) { free(p); }
 // pairwise
 // ---------------------------------------------------------------------------
 template <typename T>
-static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, T *out) {
+static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, T *out,
+                         bool cosine = false) {
     if (!out && n) return fail(PN_ERR_INVALID, "out is NULL");
     if (n == 0) return PN_OK;
     if (n < 2) {  // src/distance.rs:63-65
@@ -1473,17 +1474,24 @@ static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
     const size_t ld = pick_ld(cols), n_pad = round_up(n, (size_t)kRowPad);
-    T *d_x = nullptr, *d_p = nullptr, *d_o = nullptr;
+    if (cosine && n > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many rows");
+    T *d_x = nullptr, *d_p = nullptr, *d_o = nullptr, *d_n = nullptr;
     int rc = upload_rows<T>(x, n, cols, row_stride, &d_x);
     do {
         if (rc != PN_OK) break;
         if (hipMalloc((void **)&d_p, n_pad * ld * sizeof(T)) != hipSuccess ||
-            hipMalloc((void **)&d_o, n * n * sizeof(T)) != hipSuccess) {
+            hipMalloc((void **)&d_o, n * n * sizeof(T)) != hipSuccess ||
+            (cosine && hipMalloc((void **)&d_n, n * sizeof(T)) != hipSuccess)) {
             rc = fail(PN_ERR_NOMEM, "hipMalloc pairwise failed");
             break;
         }
         hipError_t e = Ops<T>::pack(d_x, n, cols, cols ? cols : 1, d_p, n_pad, ld, nullptr);
-        if (e == hipSuccess)
+        if (e == hipSuccess && cosine)
+            e = (sizeof(T) == 4) ? launch_cosine_pairwise_f32((const float *)d_p, n, (int)cols, ld, (float *)d_n,
+                                                              (float *)d_o, nullptr)
+                                 : launch_cosine_pairwise_f64((const double *)d_p, n, (int)cols, ld, (double *)d_n,
+                                                              (double *)d_o, nullptr);
+        else if (e == hipSuccess)
             e = (sizeof(T) == 4) ? launch_exact_pairwise_f32((const float *)d_p, n, (int)cols, ld, (float *)d_o, nullptr)
                                  : launch_exact_pairwise_f64((const double *)d_p, n, (int)cols, ld, (double *)d_o, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1493,7 +1501,16 @@ static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride
     if (d_x) (void)hipFree(d_x);
     if (d_p) (void)hipFree(d_p);
     if (d_o) (void)hipFree(d_o);
+    if (d_n) (void)hipFree(d_n);
     return rc;
+}
+extern "C" int pn_pairwise_cosine_f32(const float *x, size_t n, size_t cols, ptrdiff_t row_stride, int device,
+                                      float *out) {
+    return pairwise_impl<float>(x, n, cols, row_stride, device, out, true);
+}
+extern "C" int pn_pairwise_cosine_f64(const double *x, size_t n, size_t cols, ptrdiff_t row_stride, int device,
+                                      double *out) {
+    return pairwise_impl<double>(x, n, cols, row_stride, device, out, true);
 }
 extern "C" int pn_pairwise_f32(const float *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, float *out) {
     return pairwise_impl<float>(x, n, cols, row_stride, device, out);

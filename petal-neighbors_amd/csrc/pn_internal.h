@@ -65,6 +65,11 @@ hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ld
                                    hipStream_t s);
 hipError_t launch_exact_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *out, hipStream_t s);
 hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *out, hipStream_t s);
+// distance::pairwise under the Cosine metric; norms: n elements of scratch
+hipError_t launch_cosine_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *norms, float *out,
+                                      hipStream_t s);
+hipError_t launch_cosine_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *norms, double *out,
+                                      hipStream_t s);
 
 // ---- select.hip
 // Exact mode: keys are exact distance keys; picks the kout smallest (key, idx).

@@ -1,7 +1,7 @@
 """Host mirror of petal-neighbors' ``distance`` module (reference src/distance.rs).
 
-``Euclidean`` is the zero-sized metric tag with the four ``Metric<A>`` methods
-(src/distance.rs:9-14, 21-55); ``pairwise`` is the batched n x n matrix
+``Euclidean`` / ``Cosine`` are the zero-sized metric tags with the four ``Metric<A>`` methods
+(src/distance.rs:9-14, 21-55, 76-122); ``pairwise`` is the batched n x n matrix
 (src/distance.rs:58-74) and runs on the GPU.  Everything calls the C ABI
 (libpetal_mi355x.so); nothing is computed in Python/NumPy.
 """
@@ -64,10 +64,44 @@ class Euclidean:
         return np.float64(_lib.lib().pn_distance_to_rdistance_f64(float(d)))
 
 
+class Cosine:
+    """``distance::Cosine`` (src/distance.rs:76-122): ``1 - dot / (|x1| |x2|)`` with the reference's three
+    sequential sums; ``rdistance`` and both conversions are the identity there.  Served as a pair metric and by
+    ``pairwise``; ``BallTree.new(points, Cosine())`` is not offered (cosine distance is not a metric: the reference's
+    pruned walk returns walk-dependent answers under it, and this engine replaces that walk)."""
+
+    def __eq__(self, other):
+        return isinstance(other, Cosine)
+
+    def __hash__(self):
+        return hash("Cosine")
+
+    def __repr__(self):
+        return "Cosine"
+
+    def distance(self, x1, x2):
+        a = _as_float_array(x1)
+        b = _as_float_array(x2, a.dtype)
+        if a.ndim != 1 or b.ndim != 1:
+            raise ValueError("Metric::distance takes two 1-D views")
+        sfx = "f32" if a.dtype == np.float32 else "f64"
+        return a.dtype.type(getattr(_lib.lib(), f"pn_cosine_{sfx}")(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0]))
+
+    def rdistance(self, x1, x2):  # src/distance.rs:109-112
+        return self.distance(x1, x2)
+
+    def rdistance_to_distance(self, d):  # src/distance.rs:113-116
+        return d
+
+    def distance_to_rdistance(self, d):  # src/distance.rs:118-121
+        return d
+
+
 def pairwise(x, metric=None, device: int = 0):
     """``distance::pairwise(x, &metric)`` (src/distance.rs:58-74) on the GPU."""
-    if metric is not None and not isinstance(metric, Euclidean):
-        raise NotImplementedError("only the Euclidean metric is on the MI355X path")
+    if metric is not None and not isinstance(metric, (Euclidean, Cosine)):
+        raise NotImplementedError("only the Euclidean and Cosine metrics are on the MI355X path")
+    fn = "pn_pairwise_cosine" if isinstance(metric, Cosine) else "pn_pairwise"
     a = np.asarray(x)
     if a.ndim != 2:
         raise ValueError("pairwise takes a 2-D array")
@@ -75,6 +109,6 @@ def pairwise(x, metric=None, device: int = 0):
     n, d = a.shape
     sfx = "f32" if a.dtype == np.float32 else "f64"
     out = np.empty((n, n), dtype=a.dtype)
-    rc = getattr(_lib.lib(), f"pn_pairwise_{sfx}")(a.ctypes.data, n, d, d, device, out.ctypes.data)
+    rc = getattr(_lib.lib(), f"{fn}_{sfx}")(a.ctypes.data, n, d, d, device, out.ctypes.data)
     check(rc)
     return out

@@ -391,6 +391,49 @@ def test_pairwise_vs_oracle(pn, oracle_mod, dtype):
         assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0)
 
 
+def _eq_bits_or_nan(a, b):
+    """bit-identical except that a NaN only has to be a NaN (0/0 has a different sign bit on x86 and on the GPU)"""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and a[~na].tobytes() == b[~nb].tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cosine_metric_and_pairwise_vs_oracle(pn, oracle_mod, kats, dtype):
+    """distance::Cosine (src/distance.rs:76-122): pair metric on the host, pairwise on the GPU, both the oracle's
+    bit for bit; the reference's own cosine test vectors; zero vectors give NaN as in the reference (0/0)."""
+    m = pn.distance.Cosine()
+    n_vec = 0
+    for v in kats["vectors"]:
+        for op in v["ops"]:
+            if op["op"] != "cosine":
+                continue
+            dt = np.float32 if op.get("dtype") == "f32" else np.float64
+            got = m.distance(np.array(op["a"], dtype=dt), np.array(op["b"], dtype=dt))
+            assert abs(float(got) - op["expect"]) <= op["tol"], op
+            assert m.rdistance(np.array(op["a"], dtype=dt), np.array(op["b"], dtype=dt)) == got
+            n_vec += 1
+    assert n_vec >= 6
+    assert m.rdistance_to_distance(dtype(0.25)) == dtype(0.25) and m.distance_to_rdistance(dtype(0.25)) == dtype(0.25)
+    assert m == pn.distance.Cosine() and m != pn.distance.Euclidean()
+    for n, dim in ((1, 3), (2, 2), (65, 7), (300, 128), (130, 131), (40, 768)):
+        x = (uniform((n, dim), 61 + n, dtype) - dtype(0.3)).astype(dtype)
+        if n > 10:
+            x[5] = 0  # a zero vector: 0/0 -> NaN in its row and column (not on the diagonal)
+            x[7] = x[3] * dtype(2)  # parallel vectors
+        got = pn.distance.pairwise(x, m)
+        want = oracle_mod.pairwise_cosine(x)
+        assert _eq_bits_or_nan(got, want), (n, dim)
+        assert np.all(np.diag(got) == 0)
+        for i, j in ((0, n - 1), (n // 2, n // 3), (3 % n, 7 % n)):
+            if i != j:
+                assert _eq_bits_or_nan(np.array([m.distance(x[i], x[j])]), np.array([want[i, j]])), (n, dim, i, j)
+    # unequal lengths: the dot product zips (shorter length), each norm runs over its own vector
+    a, b = uniform((9,), 1, dtype), uniform((5,), 2, dtype)
+    assert m.distance(a, b).tobytes() == oracle_mod.cosine(a, b).tobytes()
+    with pytest.raises(NotImplementedError):
+        pn.BallTree.new(uniform((10, 3), 3, dtype), m)
+
+
 # --------------------------------------------------------- full-size properties
 def test_full_size_headline_properties(pn, oracle_mod):
     """BASELINE.json configs[1]: 1M x 128 f32, k=10 (2 048 of the 10 000 queries to bound time).

@@ -39,6 +39,11 @@ def test_all_reference_vectors(oracle_mod, kats):
                     o.Tree(pts)
                 assert str(ei.value) == kats["error_strings"][op["expect"]], where
                 continue
+            if kind == "cosine":  # distance == rdistance for Cosine (src/distance.rs:109-112)
+                dt = np.float32 if op.get("dtype") == "f32" else np.float64
+                got = o.cosine(np.array(op["a"], dtype=dt), np.array(op["b"], dtype=dt))
+                assert _close(got, op["expect"], op["tol"]), where
+                continue
             if kind == "pairwise":
                 got = o.pairwise(pts)
                 assert np.array_equal(got, np.array(op["expect"])), where  # assert_eq! in the reference
@@ -212,3 +217,35 @@ def test_fill_uniform_is_24_bit(oracle_mod):
     assert np.all((x * 16777216.0) == np.floor(x * 16777216.0))
     y = oracle_mod.fill_uniform(100, 0x5EED0001, first_ctr=10)
     assert np.array_equal(y, x[10:110])
+
+
+def test_cosine_restatement(oracle_mod):
+    """Cosine::distance (src/distance.rs:85-107) against an independent f64 evaluation, and its structure: three
+    sequential sums, zip truncation for the dot product only, zero vector -> NaN, pairwise mirrored with zero diagonal."""
+    o = oracle_mod
+    rng = np.random.default_rng(5)
+    for dim in (1, 2, 7, 128, 769):
+        a, b = rng.standard_normal(dim), rng.standard_normal(dim)
+        want = 1.0 - float(a @ b) / (np.sqrt(float(a @ a)) * np.sqrt(float(b @ b)))
+        assert abs(float(o.cosine(a, b)) - want) < 1e-12
+        a32, b32 = a.astype(np.float32), b.astype(np.float32)
+        assert abs(float(o.cosine(a32, b32)) - want) < 1e-4
+        # the f32 fold step by step
+        dot = n1 = n2 = np.float32(0)
+        for k in range(dim):
+            dot = np.float32(dot + np.float32(a32[k] * b32[k]))
+        for k in range(dim):
+            n1 = np.float32(n1 + np.float32(a32[k] * a32[k]))
+        for k in range(dim):
+            n2 = np.float32(n2 + np.float32(b32[k] * b32[k]))
+        ref = np.float32(np.float32(1) - np.float32(dot / np.float32(np.sqrt(n1) * np.sqrt(n2))))
+        assert o.cosine(a32, b32).tobytes() == ref.tobytes()
+    assert np.isnan(o.cosine(np.zeros(3), np.ones(3)))
+    a, b = rng.standard_normal(9), rng.standard_normal(5)
+    want = 1.0 - float(a[:5] @ b) / (np.sqrt(float(a @ a)) * np.sqrt(float(b @ b)))
+    assert abs(float(o.cosine(a, b)) - want) < 1e-12
+    x = rng.standard_normal((6, 4))
+    pw = o.pairwise_cosine(x)
+    assert np.array_equal(pw, pw.T) and np.all(np.diag(pw) == 0)
+    assert pw[1, 4] == o.cosine(x[1], x[4])
+    assert np.array_equal(o.pairwise_cosine(x[:1]), np.zeros((1, 1)))
