@@ -583,7 +583,7 @@ struct Bf16Plan {
     bool wide;
     int per_tile;
 };
-// Wide rows: one workgroup per CU (144 KiB of LDS), a grid of q_tiles * per_tile workgroups, non-persistent.  per_tile
+// Wide rows: one workgroup per CU (128 KiB of LDS), a grid of q_tiles * per_tile workgroups, non-persistent.  per_tile
 // is chosen for the fullest last round of workgroups among the values that leave every run at least 8 row tiles.
 static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
     Bf16Plan p{};
