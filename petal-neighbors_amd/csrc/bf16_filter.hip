@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 //    kernel (bf_slow, bf_compact); the other wave of the SIMD keeps the matrix pipe busy meanwhile;
 //  * the two row halves of a workgroup are two SEGMENTS of the query (own buffers, own thresholds): the partition
 //    is (query tile, row range) per workgroup, per_tile workgroups per query tile, 2 per_tile segments per query;
-//  * thresholds start from a scout pass over the run's first tiles (own seed only).
+//  * thresholds start from a scout pass over the run's first tiles: the wave's own seed, or -- shared scout, as for
+//    narrow rows -- a scout-only launch whose lists bf16_seed_kernel merges per query over all segments.
 // ---------------------------------------------------------------------------
 template <int M, bool RAD>
 __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restrict__ img, uint32_t n_tiles,
@@ -783,7 +784,8 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                                                            uint2 *__restrict__ cand, uint32_t *__restrict__ ccnt,
                                                            uint32_t *__restrict__ ctau, size_t nq_pad,
                                                            uint32_t per_tile, uint32_t scout_max,
-                                                           const uint32_t *__restrict__ tau_init) {
+                                                           const uint32_t *__restrict__ tau_init,
+                                                           float *__restrict__ scout_out) {
     constexpr uint32_t CAP = 64u * M;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     char *lds = reinterpret_cast<char *>(smem_raw);  // [2][kWStage]
@@ -809,6 +811,14 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     float tau0 = inf, tau1 = inf;
     uint32_t cnt0 = 0, cnt1 = 0;
     if (rt0 >= rt1) {  // more workgroups than row tiles: an empty segment
+        if (scout_out) {
+#pragma unroll
+            for (int i = 0; i < kScoutList; ++i) {
+                scout_out[((cell0 + jq) * 2 + h) * kScoutList + i] = inf;
+                scout_out[((cell0 + 32 + jq) * 2 + h) * kScoutList + i] = inf;
+            }
+            return;
+        }
         if (h == 0) {
             ccnt[cell0 + jq] = 0;
             ctau[cell0 + jq] = f2s(inf);
@@ -903,10 +913,14 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
 #ifdef PN_DIAG_BF_NOSCOUT
     t_scout = 0;
 #endif
-    if (tau_init) {  // thresholds given by the caller (radius queries: each query's fixed bound): no scouting
+    if (tau_init) {  // thresholds given by the caller (radius: each query's fixed bound; k-NN: the shared seed)
         t_scout = 0;
         tau0 = s2f(tau_init[q0 + jq]);
         tau1 = s2f(tau_init[q0 + 32 + jq]);
+    }
+    if (scout_out) {  // scout-only launch: every run contributes its lists, however short it is
+        t_scout = run_len < scout_max ? run_len : scout_max;
+        if (t_scout < 1u) t_scout = 1u;
     }
     if (t_scout) {
         float s0[kScoutList], s1[kScoutList];
@@ -936,6 +950,16 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                 insert(s0, m0);
                 insert(s1, m1);
             }
+        }
+        if (scout_out) {  // publish this lane's lists: [cell][half][kScoutList]; bf16_seed_kernel merges a query's cells
+            float *o0 = scout_out + ((cell0 + jq) * 2 + h) * kScoutList;
+            float *o1 = scout_out + ((cell0 + 32 + jq) * 2 + h) * kScoutList;
+#pragma unroll
+            for (int i = 0; i < kScoutList; ++i) {
+                o0[i] = s0[i];
+                o1[i] = s1[i];
+            }
+            return;
         }
         auto union5 = [](const float (&a)[kScoutList]) {
             const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
@@ -1090,12 +1114,10 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
                                 const uint32_t *tau_init, float *scout_out, hipStream_t s) {
     const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
     auto kern = bf16_filter_kernel<KS, M, RAD>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static LdsAttrOnce lds_attr;  // per instantiation
+    {
+        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,
                        static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,
@@ -1277,7 +1299,8 @@ hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size
 // ---- wide rows: launchers
 // cb: as for launch_bf16_filter, with cb.nseg == 2 * per_tile; the grid is (nq_pad / 256) * per_tile workgroups
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s) {
+                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                                   hipStream_t s) {
     if (!bf16_supported(dim) || !bf16_is_wide(dim) || cb.nq_pad % kWR || kp < 1 || kp + 32 > cb.cap ||
         cb.idx_stride != 2 || cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || per_tile < 1 || scout_max < 0 ||
         cb.nseg != 2 * per_tile || (radius && (cb.cap != 256 || !tau_init)))
@@ -1290,19 +1313,18 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
 #define PN_WIDE_CASE(MM, RR)                                                                                        \
     {                                                                                                               \
         auto kern = bf16_wide_kernel<MM, RR>;                                                                       \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                \
+        static LdsAttrOnce lds_attr;                                                                                \
+        {                                                                                                           \
+            const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);                         \
             if (e != hipSuccess) return e;                                                                          \
-            attr_done = true;                                                                                       \
         }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sh, s, static_cast<const char *>(img), n_tiles,   \
                            static_cast<const char *>(B), nkc, (uint32_t)kp, static_cast<uint2 *>(cb.keys), cb.cnt,  \
                            static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)per_tile, (uint32_t)scout_max,    \
-                           tau_init);                                                                               \
+                           tau_init, scout_out);                                                                    \
     }
     if (radius) {
+        if (scout_out) return hipErrorInvalidValue;
         PN_WIDE_CASE(4, true)
     } else {
         switch (cb.cap) {

@@ -634,6 +634,30 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
     // a wave scouts 128 rows per tile; the scouted rows should hold < 0.1 of the R relevant rows in expectation
     const double sm = (double)ix->n / (10.0 * R) / 128.0;
     p.scout_max = sm > 32.0 ? 32 : (int)sm;
+    // Shared scout (see bf16_plan): the rows scouted by all 2 * per_tile waves of a query form one sample; lambda =
+    // expected number of the R relevant rows in it (<= 1.2), seed_rank = smallest rank with P(Poisson >= rank) <= 1e-7
+    p.shared_scout = false;
+#ifndef PN_DIAG_NO_SHARED_SCOUT
+    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && p.nseg >= 4) {
+        const size_t run_len = r_tiles / (size_t)p.per_tile;
+        double t = 1.2 * (double)ix->n / (R * (double)p.nseg * 128.0);  // tiles per workgroup for lambda = 1.2
+        if (t > 16.0) t = 16.0;
+        if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
+        p.scout_tiles = (int)t;
+        if (p.scout_tiles >= 1) {
+            const double lam = R * (double)p.scout_tiles * 128.0 * (double)p.nseg / (double)ix->n;
+            double term = std::exp(-lam), cdf = term;
+            int rank = 1;
+            while (1.0 - cdf > 1e-7 && rank < 2 * bf16_scout_list()) {
+                term *= lam / (double)rank;
+                cdf += term;
+                ++rank;
+            }
+            p.seed_rank = rank < 5 ? 5 : rank;
+            p.shared_scout = p.seed_rank <= bf16_scout_list();
+        }
+    }
+#endif
     return p;
 }
 static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
@@ -902,9 +926,20 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     }
     const bool prof = ix->profile;
     if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    if (plan.wide) {
+    if (plan.wide && plan.shared_scout) {
+        const size_t words = cells * 2 * (size_t)bf16_scout_list();
+        PNCHK(ix->w_lists.ensure(words * sizeof(float)));
+        PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
-                                       plan.scout_max, nullptr, false, s));
+                                       plan.scout_tiles, nullptr, false, (float *)ix->w_lists.p, s));
+        if (prof) HIPCHK(hipEventRecord(ix->ev4, s));
+        HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
+        if (prof) HIPCHK(hipEventRecord(ix->ev5, s));
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile, 0,
+                                       (const uint32_t *)ix->w_seed.p, false, nullptr, s));
+    } else if (plan.wide) {
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
+                                       plan.scout_max, nullptr, false, nullptr, s));
     } else if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
         PNCHK(ix->w_lists.ensure(words * sizeof(float)));
@@ -1341,7 +1376,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
     if (wide)
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, per_tile, 0,
-                                       (const uint32_t *)ix->w_seed.p, true, s));
+                                       (const uint32_t *)ix->w_seed.p, true, nullptr, s));
     else
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
                                   (const uint32_t *)ix->w_seed.p, true, nullptr, s));

@@ -284,12 +284,10 @@ static hipError_t launch_one(const float *P, const float *pnorm, size_t n, const
     constexpr int LD = 8 * NKG;
     const size_t sh = (size_t)(2 * kMfP * (LD + 4) + 2 * kMfP) * sizeof(float) + 2 * kMfQ * sizeof(uint32_t);
     auto kern = mfma_filter_kernel<NKG, M>;
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static LdsAttrOnce lds_attr;  // per instantiation
+    {
+        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     dim3 grid((unsigned)(cb.nq_pad / kMfQ), (unsigned)plan.nseg), block(256);
     hipLaunchKernelGGL(kern, grid, block, sh, s, P, pnorm, n, Q, qnorm, (uint32_t)plan.kp, plan.seg_len,

@@ -899,12 +899,10 @@ static hipError_t launch_radius_t(const float *P, const float *pnorm, uint32_t n
                                   uint32_t *ridx, size_t nq_pad, int n_wg, hipStream_t s) {
     const size_t sh = (size_t)(2 * kV2P * V2Ctx<NKG>::STR + 2 * kV2P) * sizeof(float);
     auto kern = mfma_radius_kernel<NKG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static LdsAttrOnce lds_attr;  // per instantiation
+    {
+        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles, tau_excl, cap,
                        rcnt, ridx, nq_pad);
@@ -947,12 +945,10 @@ static hipError_t launch_v2(const float *P, const float *pnorm, uint32_t n_tiles
     const size_t sh = (size_t)(2 * kV2P * V2Ctx<NKG>::STR + 2 * kV2P) * sizeof(float) +
                       (size_t)((GC ? 0 : 2 * kV2Q * 64) + 2 * kV2Q) * sizeof(uint32_t);
     auto kern = mfma_filter_v2_kernel<NKG, GC, M>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static LdsAttrOnce lds_attr;  // per instantiation
+    {
+        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, P, pnorm, n_tiles, Q, qnorm, q_tiles, kp,
                        static_cast<uint32_t *>(cb.keys), cb.idx, cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad,

@@ -3,10 +3,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 
 namespace pn {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to
+// the device's copy of the kernel, and index handles on different devices -- or threads -- may launch the same
+// instantiation.  One static instance per launcher.
+struct LdsAttrOnce {
+    std::atomic<uint64_t> done{0};
+    hipError_t ensure(const void *kern, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
 
 // ---- tiling constants of the exact scan (exact_scan.hip)
 constexpr int kTileQ = 64;    // queries per workgroup tile
@@ -174,9 +192,11 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
                               hipStream_t s);
 // wide rows: grid of (nq_pad / 256) * per_tile workgroups, cb.nseg == 2 * per_tile (a workgroup's two row halves are
 // two segments), every cell written; scout_max in 256-row tiles
-// tau_init (nullable): starting thresholds per query; radius: fixed thresholds, overflow instead of compaction (cap 256)
+// tau_init (nullable): starting thresholds per query; radius: fixed thresholds, overflow instead of compaction (cap 256);
+// scout_out (nullable): scout-only launch, lists as for launch_bf16_filter
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, hipStream_t s);
+                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                                   hipStream_t s);
 int bf16_scout_list();
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);
