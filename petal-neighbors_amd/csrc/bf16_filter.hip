@@ -507,7 +507,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #pragma unroll
         for (int i0 = 0; i0 < CP; i0 += 4) {
             const int i = i0 + wave;
+#ifdef PN_DIAG_BF_NODMA  // timing-only: tiles are never loaded
+            if (false)
+#else
             if (i < CP)
+#endif
                 __builtin_amdgcn_global_load_lds((glb_void_b *)(src + i * 1024), (lds_void_b *)(dst + i * 1024), 16, 0,
                                                  0);
         }
@@ -703,7 +707,9 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             bf_wait_dma(ns);
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PN_DIAG_BF_NOBARRIER  // NOBARRIER is timing-only
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
         }
         {  // drain: both blocks of the last tile
