@@ -504,17 +504,21 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     auto dma_tile = [&](uint32_t rt, int buf) {
         const char *src = img + (size_t)rt * (size_t)TB + lane * 16;
         char *dst = tiles + buf * TB;
-#pragma unroll
-        for (int i0 = 0; i0 < CP; i0 += 4) {
-            const int i = i0 + wave;
-#ifdef PN_DIAG_BF_NODMA  // timing-only: tiles are never loaded
-            if (false)
-#else
-            if (i < CP)
+        // wave w moves the consecutive pieces [w P, w P + P): one address register and one M0 value serve four pieces
+        // through the instruction's immediate offset (which advances the global and the LDS address alike)
+        constexpr int P = (CP + 3) / 4;
+        const char *ws = src + wave * (P * 1024);
+        char *wd = dst + wave * (P * 1024);
+        const int n_mine = CP - wave * P < P ? CP - wave * P : P;  // pieces of this wave (the last wave may have fewer)
+#ifndef PN_DIAG_BF_NODMA  // NODMA is timing-only: tiles are never loaded
+        static_assert(P <= 5, "piece schedule written out for up to five pieces per wave");
+        if (0 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 0, 0);
+        if (P > 1 && 1 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 1024, 0);
+        if (P > 2 && 2 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 2048, 0);
+        if (P > 3 && 3 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 3072, 0);
+        if (P > 4 && 4 < n_mine)
+            __builtin_amdgcn_global_load_lds((glb_void_b *)(ws + 4096), (lds_void_b *)(wd + 4096), 16, 0, 0);
 #endif
-                __builtin_amdgcn_global_load_lds((glb_void_b *)(src + i * 1024), (lds_void_b *)(dst + i * 1024), 16, 0,
-                                                 0);
-        }
     };
 
     while (u0 < u1) {
