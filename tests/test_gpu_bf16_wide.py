@@ -138,3 +138,17 @@ def test_wide_query_radius(pn, oracle_mod, engine):
     i5, d5 = tree.query(q, 5)
     got = tree.query_radius(q, float(d5[4]))
     assert list(got) == sorted(int(i) for i in i5[:4])
+
+
+def test_wide_partition_edge_cases(pn, oracle_mod):
+    """few row tiles (empty segments), one query tile against many row ranges, the segment cap option, large k'"""
+    from petal_neighbors_amd import _lib
+    # 3 row tiles, 700 queries (3 query tiles): runs of one tile, no scout
+    _check(pn, oracle_mod, uniform((700, 160), 1), uniform((700, 160), 2), 3)
+    # one query against 40 000 rows: 1 query tile x up to 32 row ranges
+    _check(pn, oracle_mod, uniform((40000, 136), 3), uniform((1, 136), 4), 10)
+    # segment cap: at most 2 segments per query (one workgroup per query tile)
+    _check(pn, oracle_mod, uniform((30000, 192), 5), uniform((300, 192), 6), 5, opts={_lib.PN_OPT_SEGMENTS: 2})
+    # k = 150 (k' beyond 128 slots: 256-slot buffers)
+    tree, st = _check(pn, oracle_mod, uniform((25000, 144), 7), uniform((70, 144), 8), 150)
+    assert st["queries"] == 70
