@@ -783,8 +783,9 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 //    below keeps them (and shares every corpus tile between the workgroups of an XCD);
 //  * after the last chunk of a row tile the eight blocks are tagged, reduced and filtered exactly as in the narrow
 //    kernel (bf_slow, bf_compact); the other wave of the SIMD keeps the matrix pipe busy meanwhile;
-//  * the two row halves of a workgroup are two SEGMENTS of the query (own buffers, own thresholds): the partition
-//    is (query tile, row range) per workgroup, per_tile workgroups per query tile, 2 per_tile segments per query;
+//  * the two row halves of a workgroup are two SEGMENTS of the query (own buffers, own thresholds); the partition is
+//    the balanced persistent one of the narrow kernel (equal slices of the (query tile, row tile) list, one
+//    workgroup per CU), so a query has 2 x (workgroups touching its tile) segments;
 //  * thresholds start from a scout pass over the run's first tiles: the wave's own seed, or -- shared scout, as for
 //    narrow rows -- a scout-only launch whose lists bf16_seed_kernel merges per query over all segments.
 // ---------------------------------------------------------------------------
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                                                            const char *__restrict__ Bimg, uint32_t nkc, uint32_t kp,
                                                            uint2 *__restrict__ cand, uint32_t *__restrict__ ccnt,
                                                            uint32_t *__restrict__ ctau, size_t nq_pad,
-                                                           uint32_t per_tile, uint32_t scout_max,
+                                                           uint32_t scout_max,
                                                            const uint32_t *__restrict__ tau_init,
                                                            float *__restrict__ scout_out) {
     constexpr uint32_t CAP = 64u * M;
@@ -806,37 +807,39 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     const int qg = wave & 3, rh = wave >> 2;
 
     // Logical workgroup: hardware block b runs on XCD b % 8.  Giving each XCD a contiguous range of logical
-    // workgroups puts the per_tile row ranges of a few query tiles on one L2: those query tiles' chunks stay
-    // resident there and every corpus tile is fetched once per XCD for all the query tiles that walk it together.
+    // workgroups puts a few query tiles' row ranges on one L2 (their chunks are re-read from there) and lets
+    // workgroups of different query tiles that walk the same rows share each corpus tile.
     uint32_t w = blockIdx.x;
     const uint32_t W = gridDim.x;
     if ((W & 7u) == 0) w = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
-    const uint32_t qt = w / per_tile, sg = w % per_tile;
-    const uint32_t rt0 = (uint32_t)((unsigned long long)sg * n_tiles / per_tile);
-    const uint32_t rt1 = (uint32_t)((unsigned long long)(sg + 1) * n_tiles / per_tile);
+    // Balanced persistent partition (as bf16_filter_kernel): the work is the list of (query tile, row tile) units in
+    // query-major order, workgroup w owns the contiguous slice [w U / W, (w+1) U / W) and walks it in runs that stay
+    // inside one query tile.  Segment of a run = ordinal of the workgroup among those touching that query tile.
+    const unsigned long long U = (unsigned long long)(nq_pad / kWR) * n_tiles, Wn = W;
+    unsigned long long u0 = (unsigned long long)w * U / Wn;
+    const unsigned long long u1 = (unsigned long long)(w + 1) * U / Wn;
+    const float inf = __uint_as_float(0x7F800000u);
+
+    int slot_off[4];  // byte offset of this lane's fragment of step s inside its row (swizzled slot 2s + h)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) slot_off[s] = (int)(((unsigned)(2 * s + h) ^ bf_wide_swz((size_t)jq)) * 16u);
+    int st = 0;       // stage that holds (or is receiving) the next chunk to contract
+    uint32_t ns = 0;  // vector-memory instructions issued since this wave's last LDS-DMA (bf_wait_dma)
+    f32x16 acc[4][2];
+
+    while (u0 < u1) {
+    const uint32_t qt = (uint32_t)(u0 / n_tiles);
+    const unsigned long long v_begin = (unsigned long long)qt * n_tiles, v_end = v_begin + n_tiles;
+    const unsigned long long run_end = u1 < v_end ? u1 : v_end;
+    const uint32_t rt0 = (uint32_t)(u0 - v_begin), rt1 = (uint32_t)(run_end - v_begin);
+    unsigned long long wf = v_begin * Wn / U;  // first workgroup touching query tile qt
+    while ((wf + 1) * U / Wn <= v_begin) ++wf;
+    while (wf > 0 && wf * U / Wn > v_begin) --wf;
+    const uint32_t sg = (uint32_t)(w - wf);
     const size_t q0 = (size_t)qt * kWR + (size_t)qg * 64;                 // first query of this wave
     const size_t cell0 = (size_t)(sg * 2 + rh) * nq_pad + q0;             // its (segment, query) cell
-
-    const float inf = __uint_as_float(0x7F800000u);
     float tau0 = inf, tau1 = inf;
     uint32_t cnt0 = 0, cnt1 = 0;
-    if (rt0 >= rt1) {  // more workgroups than row tiles: an empty segment
-        if (scout_out) {
-#pragma unroll
-            for (int i = 0; i < kScoutList; ++i) {
-                scout_out[((cell0 + jq) * 2 + h) * kScoutList + i] = inf;
-                scout_out[((cell0 + 32 + jq) * 2 + h) * kScoutList + i] = inf;
-            }
-            return;
-        }
-        if (h == 0) {
-            ccnt[cell0 + jq] = 0;
-            ctau[cell0 + jq] = f2s(inf);
-            ccnt[cell0 + 32 + jq] = 0;
-            ctau[cell0 + 32 + jq] = f2s(inf);
-        }
-        return;
-    }
 
     // LDS-DMA of one stage: 64 pieces of 1 KiB, eight per wave
     const bool is_a = wave < 4;
@@ -853,12 +856,6 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             __builtin_amdgcn_global_load_lds((glb_void_b *)(src + i * 1024), (lds_void_b *)(dst + i * 1024), 16, 0, 0);
     };
 
-    int slot_off[4];  // byte offset of this lane's fragment of step s inside its row (swizzled slot 2s + h)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) slot_off[s] = (int)(((unsigned)(2 * s + h) ^ bf_wide_swz((size_t)jq)) * 16u);
-    int st = 0;       // stage that holds (or is receiving) the next chunk to contract
-    uint32_t ns = 0;  // vector-memory instructions issued since this wave's last LDS-DMA (bf_wait_dma)
-    f32x16 acc[4][2];
     // contraction of row tile rt (its chunk 0 is already on its way into stage st); rt_end: end of the tile sequence
     auto contract = [&](uint32_t rt, uint32_t rt_end) {
 #pragma unroll
@@ -969,7 +966,8 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                 o0[i] = s0[i];
                 o1[i] = s1[i];
             }
-            return;
+            u0 = run_end;
+            continue;
         }
         auto union5 = [](const float (&a)[kScoutList]) {
             const float b1 = __shfl_xor(a[0], 32), b2 = __shfl_xor(a[1], 32), b3 = __shfl_xor(a[2], 32),
@@ -1041,6 +1039,8 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
         ccnt[cell0 + 32 + jq] = cnt1;
         ctau[cell0 + 32 + jq] = f2s(tau1);
     }
+    u0 = run_end;
+    }  // runs
 }
 
 #ifdef PN_DIAG_BF_COUNT
@@ -1307,18 +1307,24 @@ hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size
 }
 
 // ---- wide rows: launchers
-// cb: as for launch_bf16_filter, with cb.nseg == 2 * per_tile; the grid is (nq_pad / 256) * per_tile workgroups
+// cb: as for launch_bf16_filter, with cb.nseg >= bf16_wide_segments(q_tiles, n_wg); cells without a writer must
+// read "empty" (cnt 0, tau +inf, lists +inf) unless n_wg is a multiple of the number of query tiles
+int bf16_wide_segments(size_t q_tiles, int n_wg) {  // cells per query: two row halves per touching workgroup
+    if (n_wg > 0 && (size_t)n_wg % q_tiles == 0) return 2 * (int)((size_t)n_wg / q_tiles);  // aligned: exact
+    return 2 * mfma_v2_max_segments(q_tiles, n_wg);
+}
+
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                                   int n_wg, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                                    hipStream_t s) {
     if (!bf16_supported(dim) || !bf16_is_wide(dim) || cb.nq_pad % kWR || kp < 1 || kp + 32 > cb.cap ||
-        cb.idx_stride != 2 || cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || per_tile < 1 || scout_max < 0 ||
-        cb.nseg != 2 * per_tile || (radius && (cb.cap != 256 || !tau_init)))
+        cb.idx_stride != 2 || cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || n_wg < 1 || scout_max < 0 ||
+        cb.nseg < bf16_wide_segments(cb.nq_pad / kWR, n_wg) || (radius && (cb.cap != 256 || !tau_init)))
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kWR - 1) / kWR);
     const uint32_t nkc = (uint32_t)bf16_wide_chunks(bf16_ks_for(dim));
-    const size_t grid = cb.nq_pad / kWR * (size_t)per_tile;
-    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if ((unsigned long long)n_wg > (unsigned long long)(cb.nq_pad / kWR) * n_tiles) return hipErrorInvalidValue;
+    const size_t grid = (size_t)n_wg;
     const size_t sh = (size_t)2 * kWStage;
 #define PN_WIDE_CASE(MM, RR)                                                                                        \
     {                                                                                                               \
@@ -1330,8 +1336,7 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
         }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sh, s, static_cast<const char *>(img), n_tiles,   \
                            static_cast<const char *>(B), nkc, (uint32_t)kp, static_cast<uint2 *>(cb.keys), cb.cnt,  \
-                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)per_tile, (uint32_t)scout_max,    \
-                           tau_init, scout_out);                                                                    \
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, (uint32_t)scout_max, tau_init, scout_out);   \
     }
     if (radius) {
         if (scout_out) return hipErrorInvalidValue;

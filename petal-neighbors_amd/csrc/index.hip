@@ -583,15 +583,20 @@ struct Bf16Plan {
     bool wide;
     int per_tile;
 };
-// Wide rows: one workgroup per CU (128 KiB of LDS), a grid of q_tiles * per_tile workgroups, non-persistent.  per_tile
-// is chosen for the fullest last round of workgroups among the values that leave every run at least 8 row tiles.
+// Wide rows: one workgroup per CU at a time (128 KiB of LDS), a whole number of workgroups per query tile: every cell
+// then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
+// same rows at the same time, which is what lets them share corpus tiles in L2 (1M x 768, 10^4 queries: 240 aligned
+// workgroups 15.0 ms, 256 balanced ones 15.6 ms).  The kernel itself takes any number of workgroups.
 static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
     Bf16Plan p{};
     p.wide = true;
     p.split = 1;
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 255) / 256;
+    // c workgroups per query tile, each a row range: the fewest within 8 % of the best CU occupancy among those that
+    // leave every run at least 8 row tiles (every run pays a scout pass and a pipeline fill, every segment adds k'
+    // candidates to the query's re-rank).  More query tiles than CUs: the grid runs in rounds; a persistent balanced
+    // partition (256 equal slices) was measured slower there too (configs[3] on one GPU: 1.78 s vs 1.70 s).
     const size_t n_cu = (size_t)ix->n_cu;
-    // share of the CUs' time that is used by q_tiles * c equal workgroups, run in rounds of n_cu
     auto eff_of = [&](size_t c) {
         const double rounds = (double)(q_tiles * c) / (double)n_cu;
         return rounds <= 1.0 ? rounds : rounds / std::ceil(rounds);
@@ -604,28 +609,30 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
         c_max = c;
         if (eff_of(c) > best_eff) best_eff = eff_of(c);
     }
-    // the fewest workgroups per query tile within 8 % of the best: every run pays a scout pass and a pipeline fill,
-    // every segment adds k' candidates to the query's re-rank
     size_t best = 1;
     while (best < c_max && eff_of(best) < best_eff - 0.08) ++best;
-    p.aligned = true;  // every (segment, query) cell is written by exactly one wave
     const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
+    double segs = 2.0;
     for (;; best = (best + 1) / 2) {
-        p.per_tile = (int)best;
-        p.n_wg = (int)(q_tiles * best);
-        p.nseg = 2 * p.per_tile;
+        size_t n_wg = q_tiles * best;
+        if (n_wg > q_tiles * r_tiles) n_wg = q_tiles * r_tiles;  // tiny corpora: one unit per workgroup at least
+        p.n_wg = (int)n_wg;
+        p.per_tile = (int)(n_wg / q_tiles > 0 ? n_wg / q_tiles : 1);  // workgroups per query tile
+        p.aligned = n_wg % q_tiles == 0;
+        p.nseg = bf16_wide_segments(q_tiles, p.n_wg);
+        segs = 2.0 * (double)p.per_tile;  // segments a query's relevant rows are spread over
         double kp;
         if (ix->filter_slots > 0)
             kp = (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
         else if (ix->bf16_level != 0)
             kp = R + 6.0 * std::sqrt(R) + 4.0;
         else {
-            const double per = R / (double)p.nseg;
+            const double per = R / segs;
             kp = per + 5.0 * std::sqrt(per) + 3.0;
             if (kp < 8.0) kp = 8.0;
         }
         p.kp = (int)std::ceil(kp);
-        p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256 && q_tiles * best <= 0x7FFFFFFFull;
+        p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256;
         p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
         // the re-rank kernel gathers all cells of a query into 64 KiB of LDS (12 B per slot + the query row)
         if (best == 1 || (size_t)p.nseg * (size_t)p.cap * 12 + (ix->dim + 8) * 4 <= 60 * 1024) break;
@@ -634,17 +641,18 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
     // a wave scouts 128 rows per tile; the scouted rows should hold < 0.1 of the R relevant rows in expectation
     const double sm = (double)ix->n / (10.0 * R) / 128.0;
     p.scout_max = sm > 32.0 ? 32 : (int)sm;
-    // Shared scout (see bf16_plan): the rows scouted by all 2 * per_tile waves of a query form one sample; lambda =
-    // expected number of the R relevant rows in it (<= 1.2), seed_rank = smallest rank with P(Poisson >= rank) <= 1e-7
+    // Shared scout (see bf16_plan): the rows scouted by all waves of a query form one sample; lambda = expected
+    // number of the R relevant rows in it (<= 1.2), seed_rank = smallest rank with P(Poisson >= rank) <= 1e-7
     p.shared_scout = false;
 #ifndef PN_DIAG_NO_SHARED_SCOUT
-    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && p.nseg >= 4) {
-        const size_t run_len = r_tiles / (size_t)p.per_tile;
-        double t = 1.2 * (double)ix->n / (R * (double)p.nseg * 128.0);  // tiles per workgroup for lambda = 1.2
+    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && segs >= 4.0) {
+        const size_t run_len = q_tiles * r_tiles / (size_t)p.n_wg;
+        double t = 1.2 * (double)ix->n / (R * segs * 128.0);  // tiles per run for lambda = 1.2
         if (t > 16.0) t = 16.0;
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
         p.scout_tiles = (int)t;
         if (p.scout_tiles >= 1) {
+            // a query tile may be touched by one workgroup more than per_tile: the sample is at most this large
             const double lam = R * (double)p.scout_tiles * 128.0 * (double)p.nseg / (double)ix->n;
             double term = std::exp(-lam), cdf = term;
             int rank = 1;
@@ -930,15 +938,17 @@ static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
         PNCHK(ix->w_lists.ensure(words * sizeof(float)));
         PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
+        if (!plan.aligned)
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg,
                                        plan.scout_tiles, nullptr, false, (float *)ix->w_lists.p, s));
         if (prof) HIPCHK(hipEventRecord(ix->ev4, s));
         HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
         if (prof) HIPCHK(hipEventRecord(ix->ev5, s));
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile, 0,
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg, 0,
                                        (const uint32_t *)ix->w_seed.p, false, nullptr, s));
     } else if (plan.wide) {
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.per_tile,
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg,
                                        plan.scout_max, nullptr, false, nullptr, s));
     } else if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
@@ -1342,12 +1352,12 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
     const bool wide = bf16_is_wide((int)ix->dim);
-    int per_tile = 1;
-    if (wide) {  // the k-NN plan's partition, at most 16 row ranges (32 segments) per query tile
-        per_tile = bf16_plan_wide(ix, nq_pad, 1).per_tile;
-        if (per_tile > 16) per_tile = 16;
+    int wide_wg = 1;
+    if (wide) {  // the k-NN plan's partition, at most 32 segments per query (the check kernel's LDS budget)
+        wide_wg = bf16_plan_wide(ix, nq_pad, 1).n_wg;
+        while (wide_wg > 1 && bf16_wide_segments(q_tiles, wide_wg) > 32) wide_wg = (wide_wg + 1) / 2;
     }
-    const int nseg = wide ? 2 * per_tile : bf16_segments(q_tiles, (int)n_wg, 1);
+    const int nseg = wide ? bf16_wide_segments(q_tiles, wide_wg) : bf16_segments(q_tiles, (int)n_wg, 1);
     const size_t cells = (size_t)nseg * nq_pad;
     const size_t kept_stride = (size_t)nseg * cap;
     // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24): every row whose reference distance is < r has a squared distance
@@ -1375,7 +1385,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     HIPCHK(launch_bf16_radius_tau((const double *)ix->w_qn.p, nq_pad, t, (uint32_t *)ix->w_seed.p, s));
     CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
     if (wide)
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, per_tile, 0,
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, wide_wg, 0,
                                        (const uint32_t *)ix->w_seed.p, true, nullptr, s));
     else
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,

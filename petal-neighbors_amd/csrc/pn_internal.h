@@ -190,12 +190,14 @@ int bf16_segments(size_t q_tiles, int n_wg, int split);
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                               hipStream_t s);
-// wide rows: grid of (nq_pad / 256) * per_tile workgroups, cb.nseg == 2 * per_tile (a workgroup's two row halves are
-// two segments), every cell written; scout_max in 256-row tiles
+// wide rows: n_wg persistent workgroups (one per CU) over equal slices of the (query tile, row tile) list;
+// cb.nseg >= bf16_wide_segments(q_tiles, n_wg) (a workgroup's two row halves are two segments); cells without a writer
+// must read "empty" unless n_wg is a multiple of q_tiles; scout_max in 256-row tiles
 // tau_init (nullable): starting thresholds per query; radius: fixed thresholds, overflow instead of compaction (cap 256);
 // scout_out (nullable): scout-only launch, lists as for launch_bf16_filter
+int bf16_wide_segments(size_t q_tiles, int n_wg);
 hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb,
-                                   int per_tile, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
+                                   int n_wg, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                                    hipStream_t s);
 int bf16_scout_list();
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
