@@ -811,7 +811,9 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     // workgroups of different query tiles that walk the same rows share each corpus tile.
     uint32_t w = blockIdx.x;
     const uint32_t W = gridDim.x;
+#ifndef PN_DIAG_BF_WIDE_NOREMAP
     if ((W & 7u) == 0) w = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
+#endif
     // Balanced persistent partition (as bf16_filter_kernel): the work is the list of (query tile, row tile) units in
     // query-major order, workgroup w owns the contiguous slice [w U / W, (w+1) U / W) and walks it in runs that stay
     // inside one query tile.  Segment of a run = ordinal of the workgroup among those touching that query tile.
