@@ -668,6 +668,29 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
 #endif
     return p;
 }
+// Narrow rows, enough work for every workgroup slot: a grid of c workgroups per query tile, run in rounds when it
+// exceeds the 2 n_cu slots -- the fewest c within 5 % of the best slot occupancy.  Whole runs only, and the resident
+// workgroups (different query tiles, same row ranges) walk the same rows at the same time and share them in L2;
+// 2 n_cu persistent equal slices straddle query tiles and walk unrelated rows (configs[2], 10^7 x 128, 10^5
+// queries, k = 100: 291 -> 255 ms; one shard of configs[4], 1.25 10^7 x 96, 10^6 queries: 2.40 -> 2.28 s).
+static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, size_t n_wg) {
+    if (ix->opt_segments != 0 || n_wg != 2 * (size_t)ix->n_cu) return n_wg;
+    const size_t slots = n_wg;
+    auto eff_of = [&](size_t c) {
+        const double rounds = (double)(q_tiles * c) / (double)slots;
+        return rounds <= 1.0 ? rounds : rounds / std::ceil(rounds);
+    };
+    size_t c_max = 1;
+    double best_eff = eff_of(1);
+    for (size_t c = 2; c <= 32; ++c) {
+        if (r_tiles / c < 32) break;
+        c_max = c;
+        if (eff_of(c) > best_eff) best_eff = eff_of(c);
+    }
+    size_t c = 1;
+    while (c < c_max && eff_of(c) < best_eff - 0.05) ++c;
+    return q_tiles * c;
+}
 static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     if (bf16_is_wide((int)ix->dim)) return bf16_plan_wide(ix, nq_pad, kout);
     Bf16Plan p{};
@@ -679,28 +702,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     if (ix->opt_segments > 0 && q_tiles * (size_t)ix->opt_segments < cap_wg) cap_wg = q_tiles * (size_t)ix->opt_segments;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
-    // With enough work for every workgroup slot: a grid of c workgroups per query tile, run in rounds when it exceeds
-    // the 2 n_cu slots -- the fewest c within 5 % of the best slot occupancy.  Whole runs only, and the resident
-    // workgroups (different query tiles, same row ranges) walk the same rows at the same time and share them in L2;
-    // 2 n_cu persistent equal slices straddle query tiles and walk unrelated rows (configs[2], 10^7 x 128, 10^5
-    // queries, k = 100: 291 -> 255 ms; one shard of configs[4], 1.25 10^7 x 96, 10^6 queries: 2.40 -> 2.28 s).
-    if (ix->opt_segments == 0 && n_wg == 2 * (size_t)ix->n_cu) {
-        const size_t slots = n_wg;
-        auto eff_of = [&](size_t c) {
-            const double rounds = (double)(q_tiles * c) / (double)slots;
-            return rounds <= 1.0 ? rounds : rounds / std::ceil(rounds);
-        };
-        size_t c_max = 1;
-        double best_eff = eff_of(1);
-        for (size_t c = 2; c <= 32; ++c) {
-            if (r_tiles / c < 32) break;
-            c_max = c;
-            if (eff_of(c) > best_eff) best_eff = eff_of(c);
-        }
-        size_t c = 1;
-        while (c < c_max && eff_of(c) < best_eff - 0.05) ++c;
-        n_wg = q_tiles * c;
-    }
+    n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);
     // a whole number of workgroups per query tile: each workgroup's slice is then ONE run.  A slice that straddles
     // a query-tile boundary is two runs, each with its own operand load, scout pass and buffer warm-up, and those
     // workgroups set the kernel's time (C2: 512 workgroups = 12.8 per tile 4.34 ms, 480 = 12 per tile 3.62 ms)
@@ -1373,6 +1375,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     if (by_work < cap_wg) cap_wg = by_work;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
+    n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);
     const bool wide = bf16_is_wide((int)ix->dim);
     int wide_wg = 1;
     if (wide) {  // the k-NN plan's partition, at most 32 segments per query (the check kernel's LDS budget)

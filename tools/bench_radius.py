@@ -1,11 +1,11 @@
-"""query_radius throughput (host API: queries up, CSR down), C2-shaped corpus (PN_RADIUS_DIM=768: wide rows).
+"""query_radius throughput (host API: queries up, CSR down), C2-shaped corpus (PN_RADIUS_DIM=768: wide rows; PN_RADIUS_N / PN_RADIUS_NQ: other sizes).
 usage: bench_radius.py [r ...]"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import petal_neighbors_amd as pn
 from petal_neighbors_amd import _lib
 L = _lib.lib()
-n, dim, nq = 1_000_000, int(os.environ.get('PN_RADIUS_DIM', '128')), 10_000
+n, dim, nq = int(os.environ.get('PN_RADIUS_N', '1000000')), int(os.environ.get('PN_RADIUS_DIM', '128')), int(os.environ.get('PN_RADIUS_NQ', '10000'))
 pts = torch.empty((n, dim), dtype=torch.float32, device='cuda:0'); qs = torch.empty((nq, dim), dtype=torch.float32, device='cuda:0')
 L.pn_fill_uniform_device_f32(pts.data_ptr(), n * dim, 0x5EED0001, 0, 0, None); L.pn_fill_uniform_device_f32(qs.data_ptr(), nq * dim, 0x5EED0002, 0, 0, None)
 torch.cuda.synchronize()
