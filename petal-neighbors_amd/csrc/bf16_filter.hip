@@ -812,7 +812,10 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     uint32_t w = blockIdx.x;
     const uint32_t W = gridDim.x;
 #ifndef PN_DIAG_BF_WIDE_NOREMAP
-    if ((W & 7u) == 0) w = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
+    {   // XCD x runs the blocks b = x, x + 8, ...: it gets the logical range that starts where XCD x - 1's ends
+        const uint32_t x = blockIdx.x & 7u, base = W >> 3, rem = W & 7u;  // XCDs 0 .. rem-1 run base + 1 blocks
+        w = x * base + (x < rem ? x : rem) + (blockIdx.x >> 3);
+    }
 #endif
     // Balanced persistent partition (as bf16_filter_kernel): the work is the list of (query tile, row tile) units in
     // query-major order, workgroup w owns the contiguous slice [w U / W, (w+1) U / W) and walks it in runs that stay
