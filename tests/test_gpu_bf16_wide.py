@@ -152,3 +152,24 @@ def test_wide_partition_edge_cases(pn, oracle_mod):
     # k = 150 (k' beyond 128 slots: 256-slot buffers)
     tree, st = _check(pn, oracle_mod, uniform((25000, 144), 7), uniform((70, 144), 8), 150)
     assert st["queries"] == 70
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 64, 66500, 5), (20000, 256, 70000, 5), (30000, 128, 140000, 3)])
+def test_many_query_tiles_run_the_grid_in_rounds(pn, oracle_mod, n, dim, nq, k):
+    """more query tiles than workgroup slots: the plan launches a grid of c workgroups per query tile that runs in
+    rounds (narrow rows: bf16_grid_wgs, wide rows: bf16_plan_wide); a sample of the queries against the oracle"""
+    pts = uniform((n, dim), 500 + dim)
+    qs = uniform((nq, dim), 600 + dim)
+    tree = pn.BallTree.euclidean(pts)
+    idx, dist = tree.query_batch(qs, k)
+    sel = np.unique(np.concatenate([np.arange(0, nq, 997), [nq - 1, nq - 2, 255, 256, 257]]))
+    oidx, odist = oracle_mod.brute_knn(pts, qs[sel], k)
+    assert dist[sel].tobytes() == odist.tobytes() and np.array_equal(idx[sel], oidx)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    st = tree.stats()
+    assert st["fallback_queries"] <= nq // 200, st
+    # radius through the same plan
+    r = float(odist[0, -1]) * 1.0000001
+    off, ids = tree.query_radius_batch(qs[:300], r)
+    for a in (0, 1, 150, 299):
+        assert np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle_mod.brute_radius(pts, qs[a], np.float32(r)))
