@@ -75,6 +75,13 @@ constexpr int kBQ = 256;  // queries per workgroup (4 waves x 64)
 constexpr int kBP = 64;   // rows per tile
 constexpr double kG = 1.0 / 8192.0;          // g = 2^-13 (accumulation-error allowance, see header)
 constexpr double kUp = 1.0 + 1.0 / 1099511627776.0;  // 1 + 2^-40: covers the f64 rounding of the norm sums
+// Column of the first of the five extra values, and the number of 16-column MFMA steps: the extras use the free
+// columns of the last data step when it has five (D mod 16 in 1..11), else a step of their own; at least two steps.
+__host__ __device__ inline int bf16_extra_col(int dim) {
+    const int room = (dim + 15) / 16 * 16 - dim;
+    return room >= 5 && dim > 16 ? dim : (dim + 15) / 16 * 16;
+}
+__host__ __device__ inline int bf16_steps(int dim) { return (bf16_extra_col(dim) + 5 + 15) / 16; }
 
 // ---------------------------------------------------------------------------
 // bf16 helpers on raw bits (host of the proofs above: every rounding direction is explicit)
@@ -128,7 +135,7 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows_img) return;
     const int CP = 2 * KS + 1, nkc = bf16_wide_chunks(KS);
-    const int E = 16 * (KS - 1);
+    const int E = bf16_extra_col(dim);
     auto at = [&](int k) -> uint16_t & { return wide ? img[bf_wide_at(r, k, nkc)] : img[r * (size_t)CP * 8 + k]; };
     if (wide) {
         for (int c = 0; c < nkc; ++c)
@@ -182,7 +189,7 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
                                          double *__restrict__ qn, uint32_t *__restrict__ qbad, int wide) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    const int K = 16 * KS, E = 16 * (KS - 1), nkc = bf16_wide_chunks(KS);
+    const int K = 16 * KS, E = bf16_extra_col(dim), nkc = bf16_wide_chunks(KS);
     auto at = [&](int k) -> uint16_t & { return wide ? B[bf_wide_at(q, k, nkc)] : B[q * (size_t)K + k]; };
     if (wide) {
         for (int c = 0; c < nkc; ++c)
@@ -1060,7 +1067,7 @@ extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int bf16_ks_for(int dim) { return (dim + 15) / 16 + 1; }
+int bf16_ks_for(int dim) { return bf16_steps(dim); }
 // D <= 128: operand-stationary kernel (bf16_filter_kernel); 128 < D <= 1024: K-chunked kernel (bf16_wide_kernel).
 // The accumulation-error allowance g = 2^-13 was checked against chains of up to 65 MFMA steps (tests/test_gpu_bf16.py).
 bool bf16_supported(int dim) { return dim >= 1 && dim <= 1024; }
