@@ -1300,12 +1300,18 @@ int bf16_scout_list() { return kScoutList; }
 
 // radius queries: per-query threshold of the filter.  A row can only be within the radius when its exact squared
 // distance is below tau_r (computed by the host with the rounding allowances of select.hip's proof), hence when
-// L' < tau_r - |q|^2_down.  out[q] = sortable key of that bound rounded up to f32 and one step beyond (strict <).
+// L' < tau_r - |q|^2_down.  out[q] = sortable key of that bound, widened by the tag tolerance, rounded up to f32 and
+// one step beyond (strict <).
 __global__ void bf16_radius_tau_kernel(const double *__restrict__ qn, size_t nq_pad, double tau_r,
                                        uint32_t *__restrict__ out) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    const double t = tau_r - qn[q];
+    // The kernel compares TAGGED bounds (low four mantissa bits = register number, bf_chain<EMB>): a tagged value is
+    // within 15 ulp = |L'| 2^-19 of the bound L' itself.  A row within the radius has L' < t; widening the threshold
+    // by |t| 2^-18 keeps its tagged bound below it in every sign case (L' >= 0: L'(1 + 2^-19) < t (1 + 2^-19);
+    // L' < 0 <= t: tagged values of negative bounds are negative; L', t < 0: L'(1 - 2^-19) < t (1 - 2^-19)).
+    double t = tau_r - qn[q];
+    t += fabs(t) * 3.814697265625e-06;
     float f = (float)t;
     if ((double)f < t) f = nextafterf(f, __uint_as_float(0x7F800000u));
     f = nextafterf(f, __uint_as_float(0x7F800000u));

@@ -226,3 +226,27 @@ def test_bf16_radius_mixed_density_falls_back_per_query(pn, oracle_mod):
     assert max(sizes) > 2500 and sorted(sizes)[len(sizes) // 2] < 50
     st = tree.stats()
     assert 1 <= st["fallback_queries"] <= 5, st  # the clump queries only, not the whole call
+
+
+def test_bf16_radius_boundary_on_tight_bounds(pn, oracle_mod):
+    """Radius thresholds vs TAGGED bounds: coordinates that bf16 represents exactly (multiples of 1/8 in
+    [0, 4)) make the filter's bound as tight as it gets -- e_p = e_q = 0, only the g-terms remain -- so rows sit as
+    close to the per-query threshold as the arithmetic allows.  With r equal to the exact distance of each query's
+    j-th neighbour (that row excluded by the strict '<', all nearer ones included) and one ulp above it (included),
+    engine bf16 must return exactly the oracle's sets."""
+    rng = np.random.default_rng(5)
+    for n, dim in ((20000, 16), (12000, 128)):
+        pts = (rng.integers(0, 32, size=(n, dim)) / 8.0).astype(np.float32)
+        qs = (rng.integers(0, 32, size=(96, dim)) / 8.0).astype(np.float32)
+        tree = pn.BallTree.euclidean(pts)
+        tree.set_engine("bf16")
+        _, d = oracle_mod.brute_knn(pts, qs, 12)
+        for j in (0, 3, 11):
+            for bump in (0, 1):
+                # one radius per call: take query a's own j-th distance for every a by calling per group of equal r
+                rs = d[:, j] if not bump else np.nextafter(d[:, j], np.float32(np.inf))
+                for r in np.unique(rs)[:24]:
+                    off, idx = tree.query_radius_batch(qs, np.float32(r))
+                    for a in np.nonzero(rs == r)[0][:4]:
+                        want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+                        assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), (n, dim, j, bump, float(r), int(a))

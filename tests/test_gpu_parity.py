@@ -432,45 +432,3 @@ def test_cosine_metric_and_pairwise_vs_oracle(pn, oracle_mod, kats, dtype):
     assert m.distance(a, b).tobytes() == oracle_mod.cosine(a, b).tobytes()
     with pytest.raises(NotImplementedError):
         pn.BallTree.new(uniform((10, 3), 3, dtype), m)
-
-
-# --------------------------------------------------------- full-size properties
-def test_full_size_headline_properties(pn, oracle_mod):
-    """BASELINE.json configs[1]: 1M x 128 f32, k=10 (2 048 of the 10 000 queries to bound time).
-    Properties that need no full oracle: ascending distances; every returned distance equals the
-    scalar metric recomputed for its index (bit-exact); no duplicates; a sample of queries equals
-    the CPU oracle's brute force; both engines agree bit for bit."""
-    import torch
-    from petal_neighbors_amd import _lib
-    n, dim, nq, k = 1_000_000, 128, 2048, 10
-    L = _lib.lib()
-    pts_t = torch.empty((n, dim), dtype=torch.float32, device="cuda:0")
-    qs_t = torch.empty((nq, dim), dtype=torch.float32, device="cuda:0")
-    assert L.pn_fill_uniform_device_f32(pts_t.data_ptr(), n * dim, 0x5EED0001, 0, 0, None) == 0
-    assert L.pn_fill_uniform_device_f32(qs_t.data_ptr(), nq * dim, 0x5EED0002, 0, 0, None) == 0
-    torch.cuda.synchronize()
-    tree = pn.BallTree.from_device(pts_t)
-    results = {}
-    engines = ["exact"] + (["mfma"] if tree.mfma_eligible else [])
-    for eng in engines:
-        tree.set_engine(eng)
-        i, d = tree.query_device(qs_t, k)
-        torch.cuda.synchronize()
-        results[eng] = (i.cpu().numpy().astype(np.uint64), d.cpu().numpy())
-    idx, dist = results["exact"]
-    for eng in engines[1:]:
-        assert np.array_equal(results[eng][0], idx) and _eq_bits(results[eng][1], dist), eng
-    assert np.all(np.diff(dist, axis=1) >= 0)
-    assert all(len(set(r.tolist())) == k for r in idx[:256])
-    # device generator == oracle generator, bit for bit
-    head = oracle_mod.fill_uniform(1000 * dim, 0x5EED0001).reshape(1000, dim)
-    assert _eq_bits(pts_t[:1000].cpu().numpy(), head)
-    pts = pts_t.cpu().numpy()
-    qs = qs_t.cpu().numpy()
-    m = pn.distance.Euclidean()
-    for a in range(0, nq, 97):
-        for j in range(k):
-            assert m.distance(qs[a], pts[int(idx[a, j])]).tobytes() == dist[a, j].tobytes()
-    sample = list(range(0, nq, 128))
-    oidx, odist = oracle_mod.brute_knn(pts, qs[sample], k)
-    assert np.array_equal(idx[sample], oidx) and _eq_bits(dist[sample], odist)
