@@ -13,15 +13,24 @@
  *   - every function returns PN_OK (0) or a PN_ERR_* code; pn_last_error()
  *     returns a thread-local message for the last failure on this thread.
  *   - strides are in ELEMENTS, not bytes.
- *   - "host" entry points take host pointers (what an ndarray hands over) and
- *     do the PCIe transfers themselves; "_device" entry points take pointers
- *     into the index's GPU memory and a hipStream_t (as void*; NULL = HIP's
- *     default stream) and enqueue work on that stream without copying inputs.
+ *   - "host" entry points take host pointers (what an ndarray hands over), do
+ *     the PCIe transfers themselves and return when the results are in the
+ *     caller's buffers; "_device" entry points take pointers into the index's
+ *     GPU memory and a hipStream_t (as void*; NULL = HIP's default stream),
+ *     ENQUEUE all their work on that stream and return without waiting for it
+ *     and without reading anything back: results are ready in stream order
+ *     (synchronise the stream, or keep enqueueing consumers on it).  Even the
+ *     second tier for queries the first tier could not prove is enqueued
+ *     unconditionally and sized by a count that stays on the device.
  *   - results are written into caller-allocated buffers; the only
  *     library-allocated result (radius CSR indices) is released with pn_free.
  *   - all query functions are re-entrant on a shared `const pn_index*`
- *     (BallTree queries take &self and `Euclidean: Sync`, src/distance.rs:19);
- *     create/destroy/set_option must not race with queries on the same handle.
+ *     (BallTree queries take &self and `Euclidean: Sync`, src/distance.rs:19):
+ *     every call works in its own pooled workspace, calls from several host
+ *     threads run side by side; create/destroy/set_option must not race with
+ *     queries on the same handle.
+ *   - statistics (pn_index_get_stats) are collected lazily: that call waits
+ *     for the device and then reads the counters the kernels kept.
  *   - there is NO CPU fallback: if no usable GPU is present every compute entry
  *     point fails with PN_ERR_DEVICE.
  *
@@ -44,7 +53,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 1
+#define PN_ABI_VERSION 2
 
 /* ---- error codes.  EMPTY / NOT_CONTIGUOUS are ArrayError (src/lib.rs:9-16). */
 enum {
@@ -55,7 +64,8 @@ enum {
     PN_ERR_DEVICE = 4,         /* HIP failure or no GPU */
     PN_ERR_NOMEM = 5,
     PN_ERR_UNSUPPORTED = 6,
-    PN_ERR_EMPTY_MATRIX = 7    /* zero columns with >= 2 rows: the reference panics "empty matrix" (src/ball_tree.rs:582) */
+    PN_ERR_EMPTY_MATRIX = 7,   /* zero columns with >= 2 rows: the reference panics "empty matrix" (src/ball_tree.rs:582) */
+    PN_ERR_COMM = 8            /* RCCL failure, or RCCL not loadable (row-sharded corpora only) */
 };
 
 /* engine selection, PN_OPT_ENGINE */
@@ -201,6 +211,59 @@ int pn_pairwise_cosine_f64(const double *x, size_t n_rows, size_t n_cols, ptrdif
 int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
                              size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
                              size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device, void *stream);
+
+/* ---- row-sharded corpora with the exchange behind the ABI (north_star: "the corpus shards by row
+ * across the 8 GPUs of one node, per-shard (idx, dist) top-k merged by one RCCL allgather over xGMI").  Shard g of G
+ * holds rows [g ceil(N/G), min(N, (g+1) ceil(N/G))); queries are replicated; each shard answers on its rows with global
+ * indices; ONE ncclAllGather per query batch of the packed per-GPU buffer {idx[nq][k'] | dist[nq][k']}; a merge kernel
+ * ordered by (distance, index).  Results are identical for every number of shards.  RCCL is loaded at run time; if
+ * it cannot be, these entry points fail with PN_ERR_COMM (everything else keeps working).
+ *
+ *   pn_sharded_create_f32             BallTree::new over `n_devices` row shards driven by THIS process: shard g lives
+ *                                     on devices[g] (ncclCommInitAll over the distinct devices; a device named several
+ *                                     times holds several shards, merged locally before the exchange).  Same
+ *                                     validation and errors as pn_index_create_f32.
+ *   pn_comm_unique_id +               one process per GPU: rank 0 gets a communicator id (PN_COMM_ID_BYTES bytes),
+ *   pn_sharded_create_rank_device_f32 the host program carries it to the other ranks, every rank passes it with ITS
+ *                                     rows (already on `device`, row-major, inner stride 1): n_local must be the
+ *                                     library's shard size for (n_total, rank, world) -- 0 for a rank beyond the corpus,
+ *                                     which still takes part in every exchange.  Collective: all ranks must call it.
+ *   pn_sharded_query_f32              host queries in, host results out (BallTree::query semantics, pn_query_f32's
+ *                                     argument meaning); with one process per GPU every rank must call it with the SAME
+ *                                     queries and every rank receives the full answer.
+ *   pn_sharded_query_device_f32       the same, queries/results in HBM of the GPU this process drives, enqueued on
+ *                                     `stream` (handles that drive exactly one GPU); batches above 131 072 queries are
+ *                                     cut into chunks whose exchange + merge overlap the next chunk's filter.
+ *   pn_sharded_query_radius_f32       BallTree::query_radius over all shards, CSR like pn_query_radius_f32.
+ * One query at a time per handle (the communicator and the exchange buffers are per-handle state, serialised inside). */
+#define PN_COMM_ID_BYTES 128
+typedef struct pn_sharded pn_sharded;
+typedef struct pn_sharded_info_t {
+    uint64_t n_points;        /* rows of the whole corpus */
+    uint64_t dim;
+    uint64_t local_first_row; /* first row held by this process */
+    uint64_t local_rows;      /* rows held by this process */
+    int32_t n_shards;         /* row shards over all processes */
+    int32_t world;            /* ranks of the RCCL communicator = GPUs */
+    int32_t local_shards;     /* shards held by this process */
+    int32_t rank;             /* this process's rank (0 with one process) */
+} pn_sharded_info_t;
+int pn_comm_unique_id(void *id_out /* PN_COMM_ID_BYTES */);
+int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                          ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out);
+int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
+                                      uint64_t n_total, int rank, int world, const void *comm_id, int device,
+                                      void *stream, pn_sharded **out);
+void pn_sharded_destroy(pn_sharded *sharded);
+int pn_sharded_info(const pn_sharded *sharded, pn_sharded_info_t *out);
+int pn_sharded_set_option(pn_sharded *sharded, int option, int64_t value); /* forwarded to every local shard */
+int pn_sharded_get_stats(const pn_sharded *sharded, pn_stats *out, int reset); /* summed over the local shards */
+int pn_sharded_query_f32(const pn_sharded *sharded, const float *queries, size_t nq, size_t q_cols,
+                         ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out);
+int pn_sharded_query_device_f32(const pn_sharded *sharded, const float *d_queries, size_t nq, size_t q_cols,
+                                size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out, void *stream);
+int pn_sharded_query_radius_f32(const pn_sharded *sharded, const float *queries, size_t nq, size_t q_cols,
+                                ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out);
 
 /* ---- diagnostic: the first-tier filter's lower bounds themselves.  bounds_out[q * n_rows + i] = L'(q, p_i)
  * for the first n_rows corpus rows (clamped to n_points), with L' + qnorm_out[q] <= |q - p_i|^2 in real

@@ -31,13 +31,15 @@ UNITS = [
     ("mfma_filter.hip", []),
     ("mfma_filter_v2.hip", []),
     ("bf16_filter.hip", []),
+    ("sharded.hip", []),
     ("metric.cpp", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 # diagnostic (timing-only) builds: PN_DIAG_FLAGS="-DPN_DIAG_NO_SLOWPATH" python build.py --force
 DIAG = os.environ.get("PN_DIAG_FLAGS", "").split()
-HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
+HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(CSRC, "topk_buffer.h"),
+           os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
 
 
 def hipcc() -> str:
@@ -74,7 +76,7 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
             cmd = [cc] + COMMON + extra + DIAG + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
-        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -120,10 +120,19 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
     const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq,
     uint32_t kp, size_t seg_len, typename KeyOf<T>::type *__restrict__ ckey, uint32_t *__restrict__ cidx,
     uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad,
-    const typename KeyOf<T>::type *__restrict__ lo_key, const uint32_t *__restrict__ lo_idx) {
+    const typename KeyOf<T>::type *__restrict__ lo_key, const uint32_t *__restrict__ lo_idx,
+    const uint32_t *__restrict__ nq_dev, uint32_t nq_off) {
     using KeyT = typename KeyOf<T>::type;
     constexpr uint32_t CAP = 64u * M;
     constexpr KeyT KMAX = KeyOf<T>::kMax;
+    // device-driven query count (second tier behind a filter: the host never reads how many queries were flagged):
+    // the grid is sized for the worst case, query tiles beyond the count leave at once
+    if (nq_dev) {
+        const uint32_t tot = *nq_dev;
+        const uint32_t c = tot > nq_off ? tot - nq_off : 0u;
+        nq = c < (uint32_t)nq ? (int)c : nq;
+        if ((size_t)blockIdx.x * kTileQ >= (size_t)nq) return;
+    }
     __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
     __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
     __shared__ KeyT taus[kTileQ];
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 template <typename T>
 static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
                                    int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                   const uint32_t *lo_idx, hipStream_t s) {
+                                   const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
     auto *ck = static_cast<KeyT *>(cb.keys);
@@ -228,7 +237,7 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
 #define PN_LAUNCH(MM)                                                                                    \
     hipLaunchKernelGGL((exact_knn_kernel<T, MM>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,          \
                        (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad, static_cast<const KeyT *>(lo_key),  \
-                       lo_idx)
+                       lo_idx, nq_dev, nq_off)
     switch (cb.cap / 64) {
         case 2: PN_LAUNCH(2); break;
         case 4: PN_LAUNCH(4); break;
@@ -242,13 +251,13 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
 
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, hipStream_t s) {
-    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, s);
 }
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, hipStream_t s) {
-    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, s);
 }
 
 // ---------------------------------------------------------------------------

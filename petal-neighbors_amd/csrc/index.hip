@@ -33,6 +33,18 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+namespace pn {
+int set_error(int code, const char *fmt, ...) {  // for the other translation units of the library (sharded.hip, tree.cpp)
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace pn
+
 #define HIPCHK(expr)                                                                            \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -58,6 +70,7 @@ extern "C" const char *pn_strerror(int code) {
         case PN_ERR_NOMEM: return "out of memory";
         case PN_ERR_UNSUPPORTED: return "unsupported";
         case PN_ERR_EMPTY_MATRIX: return "empty matrix";                    // src/ball_tree.rs:582
+        case PN_ERR_COMM: return "collective communication (RCCL) error";
         default: return "unknown error";
     }
 }
@@ -97,6 +110,36 @@ struct DevBuf {
     }
 };
 
+// Per-call scratch.  A query call takes one workspace from the index's pool for its whole duration, so calls from
+// several host threads on one handle run side by side (BallTree queries take &self, `Euclidean: Sync`,
+// src/distance.rs:19).  The *_device entry points return while their kernels are still running: `done` marks the end
+// of the last call that used the workspace, and a later call on ANOTHER stream waits for it before touching the
+// buffers (same stream: stream order is enough).
+struct Workspace {
+    DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_misc, w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
+    DevBuf w_bq, w_qn, w_qbad, w_gq, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
+    DevBuf w_hq, w_hidx, w_hdist;  // staging of the host entry points (queries up, results down)
+    hipStream_t stream = nullptr;  // the host entry points run here
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool in_flight = false;
+    DevBuf *all[27] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
+                       &w2_cnt, &w2_tau, &w_lo, &w_bq, &w_qn, &w_qbad, &w_gq, &w_gidx, &w_gdist, &w_gsel, &w_seed,
+                       &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist};
+};
+
+// What a finished chunk of a call leaves for the host to pick up LATER (never inside the call): hipEvent brackets of
+// the dominant kernel (PN_OPT_PROFILE) and the number of queries its first tier could not prove (pinned memory).
+struct CallRec {
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0/1 hot kernel, 4/5 scout|main split, 2/3 whole chunk
+    hipEvent_t done = nullptr;
+    uint32_t *h_nflag = nullptr;  // pinned
+    size_t nq = 0;
+    uint64_t call_id = 0;
+    bool pending = false, busy = false, prof = false, two_launches = false, has_flag = false, bf16_tier = false, hot = false;
+};
+constexpr int kCallRecs = 16;
+
 struct pn_index {
     int device = 0;
     int elem_bytes = 4;
@@ -104,27 +147,31 @@ struct pn_index {
     void *d_pts = nullptr;   // [n_pad][ld], zero padded
     float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
     bool mfma_ok = false;
-    void *d_img = nullptr;   // f32, D <= 128: bf16 tile images of the corpus (bf16_filter.hip)
+    void *d_img = nullptr;   // f32, D <= 1024: bf16 tile images of the corpus (bf16_filter.hip)
     float *d_mu = nullptr;   // translation vector of the bf16 tier: the corpus mean per dimension, or zero
     bool centered = false;   // d_mu != 0: translating shrinks the squared norms at least 16x
     bool bf16_ok = false;
-    int bf16_level = 0;      // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
     int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
-    hipStream_t stream = nullptr;
-    // options
+    hipStream_t stream = nullptr;  // construction
+    unsigned long long *d_stats = nullptr;  // running device counters {fallback queries, candidates, evaluations}
+    // options (set_option must not race with queries on the same handle)
     int engine = PN_ENGINE_AUTO;
     int opt_segments = 0;
     uint64_t index_base = 0;
     int profile = 0;
     int filter_slots = 0;
     int mfma_structure = 0;  // 0 auto, 1 = grid of (query tile x segment), 2 = persistent balanced partition
-    // per-call scratch, serialised by `mu`
-    mutable std::mutex mu;
-    mutable DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_fq, w_fidx, w_fdist, w_misc;
-    mutable DevBuf w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
-    mutable DevBuf w_bq, w_qn, w_qbad, w_bflags, w_gq, w_gidx, w_gdist, w_gsel, w_bmisc, w_seed, w_qstat, w_lists;  // bf16 tier
-    mutable pn_stats stats{};
-    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr, ev5 = nullptr;
+    // state that queries on a shared `const pn_index *` update: internally synchronised by `mu`
+    struct Shared {
+        std::mutex mu;
+        std::vector<Workspace *> free_ws, all_ws;
+        CallRec recs[kCallRecs];
+        unsigned next_rec = 0;
+        uint64_t next_call = 1, stats_call = 0;
+        int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
+        pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
+    };
+    mutable Shared sh;
 };
 
 struct DeviceGuard {
@@ -170,6 +217,8 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0)
             ix->n_cu = prop.multiProcessorCount;
     }
+    HIPCHK(hipMalloc((void **)&ix->d_stats, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(ix->d_stats, 0, 4 * sizeof(unsigned long long), s));
     const size_t bytes = ix->n_pad * ix->ld * sizeof(T);
     HIPCHK(hipMalloc(&ix->d_pts, bytes ? bytes : 256));
     if (sizeof(T) == 4)
@@ -356,21 +405,160 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     // queries may have been enqueued on caller streams (the *_device entry points): nothing of this
     // index may be freed while any of them is still running
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ix->w_q, &ix->w_qnorm, &ix->w_keys, &ix->w_idx, &ix->w_cnt, &ix->w_tau, &ix->w_flags,
-                      &ix->w_sel, &ix->w_fq, &ix->w_fidx, &ix->w_fdist, &ix->w_misc,
-                      &ix->w2_keys, &ix->w2_idx, &ix->w2_cnt, &ix->w2_tau, &ix->w_lo,
-                      &ix->w_bq, &ix->w_qn, &ix->w_qbad, &ix->w_bflags, &ix->w_gq, &ix->w_gidx, &ix->w_gdist,
-                      &ix->w_gsel, &ix->w_bmisc, &ix->w_seed, &ix->w_qstat, &ix->w_lists};
-    for (DevBuf *b : bufs) b->release();
+    for (Workspace *ws : ix->sh.all_ws) {
+        for (DevBuf *b : ws->all) b->release();
+        if (ws->done) (void)hipEventDestroy(ws->done);
+        if (ws->stream) (void)hipStreamDestroy(ws->stream);
+        delete ws;
+    }
+    for (CallRec &r : ix->sh.recs) {
+        for (hipEvent_t e : r.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (r.done) (void)hipEventDestroy(r.done);
+        if (r.h_nflag) (void)hipHostFree(r.h_nflag);
+    }
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
     if (ix->d_mu) (void)hipFree(ix->d_mu);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
-    hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3, ix->ev4, ix->ev5};
-    for (hipEvent_t e : evs)
-        if (e) (void)hipEventDestroy(e);
+    if (ix->d_stats) (void)hipFree(ix->d_stats);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
+}
+
+// ---------------------------------------------------------------------------
+// workspace pool and deferred per-call records
+// ---------------------------------------------------------------------------
+// Takes a workspace for a call that will enqueue on stream `s` (nullptr: the workspace's own stream is used and
+// returned).  A workspace last used on another stream is first ordered behind that use.
+static int ws_acquire(const pn_index *ix, hipStream_t *s, bool own_stream, Workspace **out) {
+    Workspace *ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        if (!ix->sh.free_ws.empty()) {
+            ws = ix->sh.free_ws.back();
+            ix->sh.free_ws.pop_back();
+        }
+    }
+    if (!ws) {
+        ws = new (std::nothrow) Workspace();
+        if (!ws) return fail(PN_ERR_NOMEM, "host allocation failed");
+        if (hipEventCreateWithFlags(&ws->done, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess) {
+            if (ws->done) (void)hipEventDestroy(ws->done);
+            delete ws;
+            return fail(PN_ERR_DEVICE, "workspace creation failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        ix->sh.all_ws.push_back(ws);
+    }
+    if (own_stream) *s = ws->stream;
+    if (ws->in_flight && ws->last_stream != *s) {
+        if (hipStreamWaitEvent(*s, ws->done, 0) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(ix->sh.mu);
+            ix->sh.free_ws.push_back(ws);
+            return fail(PN_ERR_DEVICE, "hipStreamWaitEvent failed");
+        }
+    }
+    *out = ws;
+    return PN_OK;
+}
+static void ws_release(const pn_index *ix, Workspace *ws, hipStream_t s) {
+    ws->in_flight = hipEventRecord(ws->done, s) == hipSuccess;
+    if (!ws->in_flight) (void)hipStreamSynchronize(s);  // cannot mark the end of the call: wait for it instead
+    ws->last_stream = s;
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    ix->sh.free_ws.push_back(ws);
+}
+struct WsLease {  // releases on every return path
+    const pn_index *ix;
+    Workspace *ws = nullptr;
+    hipStream_t s = nullptr;
+    explicit WsLease(const pn_index *i) : ix(i) {}
+    ~WsLease() {
+        if (ws) ws_release(ix, ws, s);
+    }
+};
+
+// folds a finished record into the host-side statistics and the tier plan (caller holds sh.mu)
+static void rec_resolve(const pn_index *ix, CallRec &r) {
+    pn_index::Shared &sh = ix->sh;
+    if (r.prof) {
+        float ms = 0, a = 0, b = 0;
+        if (r.hot) {
+            if (r.two_launches) {  // scout launch ev0..ev4, main launch ev5..ev1 (the seed kernel between them is not counted)
+                if (hipEventElapsedTime(&a, r.ev[0], r.ev[4]) == hipSuccess && hipEventElapsedTime(&b, r.ev[5], r.ev[1]) == hipSuccess) {
+                    sh.stats.hot_ms += a + b;
+                    sh.stats.hot_launches += 2;
+                }
+            } else if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) {
+                sh.stats.hot_ms += ms;
+                sh.stats.hot_launches += 1;
+            }
+        }
+        if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) {
+            if (sh.stats_call != r.call_id) {
+                sh.stats_call = r.call_id;
+                sh.stats.last_call_ms = 0.0;
+            }
+            sh.stats.last_call_ms += ms;
+        }
+    }
+    if (r.has_flag && r.bf16_tier) {
+        // a call that handed more than 1/16 of its queries to the next tier: this corpus defeats the current plan
+        // -- widen it, then turn the tier off (sticky; takes effect from the next call on)
+        const size_t nf = *r.h_nflag;
+        if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
+    }
+    r.pending = false;
+}
+// picks up every record whose chunk has finished; wait = true: all of them (the caller has synchronised the device)
+static void recs_collect(const pn_index *ix, bool wait) {
+    for (CallRec &r : ix->sh.recs) {
+        if (!r.pending) continue;
+        if (wait)
+            (void)hipEventSynchronize(r.done);
+        else if (hipEventQuery(r.done) != hipSuccess)
+            continue;
+        rec_resolve(ix, r);
+    }
+}
+// next record of the ring (its previous use, 16 chunks ago, is waited for if it is still running)
+static int rec_begin(const pn_index *ix, uint64_t call_id, size_t nq, CallRec **out) {
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    CallRec *rp = nullptr;
+    for (int i = 0; i < kCallRecs && !rp; ++i) {  // skip records another thread's chunk is still filling in
+        CallRec &c = ix->sh.recs[ix->sh.next_rec++ % kCallRecs];
+        if (!c.busy) rp = &c;
+    }
+    if (!rp) return fail(PN_ERR_UNSUPPORTED, "more than %d query chunks in flight on one index", kCallRecs);
+    CallRec &r = *rp;
+    if (r.pending) {
+        (void)hipEventSynchronize(r.done);
+        rec_resolve(ix, r);
+    }
+    if (!r.done) {
+        HIPCHK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&r.h_nflag, 64, hipHostMallocDefault));
+    }
+    if (ix->profile && !r.ev[0])
+        for (hipEvent_t &e : r.ev) HIPCHK(hipEventCreate(&e));
+    r.nq = nq;
+    r.call_id = call_id;
+    r.prof = ix->profile != 0;
+    r.two_launches = r.has_flag = r.bf16_tier = r.hot = false;
+    r.busy = true;
+    *r.h_nflag = 0;
+    *out = &r;
+    return PN_OK;
+}
+static int rec_end(const pn_index *ix, CallRec *r, hipStream_t s) {
+    const hipError_t e = hipEventRecord(r->done, s);
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    r->busy = false;
+    r->pending = e == hipSuccess;
+    if (e != hipSuccess) return fail(PN_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e));
+    return PN_OK;
 }
 
 extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
@@ -387,16 +575,16 @@ extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
 
 extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
     if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
     switch (option) {
         case PN_OPT_ENGINE:
             if (value < PN_ENGINE_AUTO || value > PN_ENGINE_BF16) return fail(PN_ERR_INVALID, "bad engine %lld", (long long)value);
             if (value == PN_ENGINE_BF16 && !ix->bf16_ok)
-                return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (f64, D > 128, fewer than 64 rows or out-of-range values)");
+                return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (f64, D > 1024, fewer than 64 rows or out-of-range values)");
             if (value == PN_ENGINE_MFMA && !ix->mfma_ok)
                 return fail(PN_ERR_UNSUPPORTED, "the MFMA filter cannot serve this index (f64, non-finite norms or unsupported shape)");
             ix->engine = (int)value;
-            ix->bf16_level = 0;
+            ix->sh.bf16_level = 0;
             return PN_OK;
         case PN_OPT_SEGMENTS:
             if (value < 0 || value > 4096) return fail(PN_ERR_INVALID, "bad segment count");
@@ -416,11 +604,25 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
     }
 }
 
+// Statistics are collected lazily: the query entry points never read anything back.  This call waits for the
+// device, folds the finished calls' records in and reads the running device counters.
 extern "C" int pn_index_get_stats(const pn_index *ix, pn_stats *out, int reset) {
     if (!ix || !out) return fail(PN_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    *out = ix->stats;
-    if (reset) ix->stats = pn_stats{};
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    HIPCHK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    recs_collect(ix, true);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (ix->d_stats) HIPCHK(hipMemcpy(h, ix->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    *out = ix->sh.stats;
+    out->fallback_queries += h[0];
+    out->candidates += h[1];
+    out->evaluations += h[2];
+    if (reset) {
+        ix->sh.stats = pn_stats{};
+        if (ix->d_stats) HIPCHK(hipMemset(ix->d_stats, 0, sizeof h));
+    }
     return PN_OK;
 }
 
@@ -461,17 +663,6 @@ static ScanPlan plan_segments(size_t n, size_t q_tiles, int cap, int forced, siz
     return ScanPlan{(int)nseg, seg_len};
 }
 
-static int ensure_events(const pn_index *ix) {
-    if (ix->ev0) return PN_OK;
-    HIPCHK(hipEventCreate(&ix->ev0));
-    HIPCHK(hipEventCreate(&ix->ev1));
-    HIPCHK(hipEventCreate(&ix->ev2));
-    HIPCHK(hipEventCreate(&ix->ev3));
-    HIPCHK(hipEventCreate(&ix->ev4));
-    HIPCHK(hipEventCreate(&ix->ev5));
-    return PN_OK;
-}
-
 // ---------------------------------------------------------------------------
 // k-NN
 // ---------------------------------------------------------------------------
@@ -481,12 +672,13 @@ template <> struct Ops<float> {
         return launch_pack_rows_f32(s, n, c, rs, d, np, ld, st);
     }
     static hipError_t knn(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, int kp,
-                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, hipStream_t s) {
-        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, s);
+                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
+                          uint32_t no, hipStream_t s) {
+        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, hipStream_t s) {
-        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, s);
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, hipStream_t s) {
+        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, s);
     }
 };
 template <> struct Ops<double> {
@@ -494,30 +686,36 @@ template <> struct Ops<double> {
         return launch_pack_rows_f64(s, n, c, rs, d, np, ld, st);
     }
     static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
-                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, hipStream_t s) {
-        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, s);
+                          size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
+                          uint32_t no, hipStream_t s) {
+        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, hipStream_t s) {
-        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, s);
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, hipStream_t s) {
+        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, s);
     }
 };
 
-// exact engine on packed queries Qp [nq_pad][ld]; results to d_idx/d_dist [nq][kout]
+// exact engine on packed queries Qp [nq_pad][ld]; results of query q to d_idx/d_dist[q * out_stride + r], r < kout.
+// second_tier: the queries are the ones a filter tier flagged -- their number lives on the device (nq_dev, of which
+// this round covers [nq_off, nq_off + nq)), the grids are sized for nq and surplus query tiles exit at once; few
+// queries are expected, so the rows are cut into as many segments as the select kernel takes.
 template <typename T>
-static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
-                     uint64_t *d_idx, T *d_dist, hipStream_t s, bool second_set, bool hot) {
+static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
+                     uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s, bool second_tier,
+                     const uint32_t *nq_dev, uint32_t nq_off, CallRec *rec) {
     using KeyT = typename KeyOf<T>::type;
     // k beyond one candidate buffer (960 slots): rounds of <= 960 neighbours, each resuming strictly
     // after the last (distance key, row) of the previous one
     const size_t kRound = 960;
     const size_t k_first = kout < kRound ? kout : kRound;
     const int cap = pick_cap(k_first);
-    const ScanPlan pl = plan_segments(ix->n, nq_pad / kTileQ, cap, ix->opt_segments, 4096, 4096);
-    DevBuf &bk = second_set ? ix->w2_keys : ix->w_keys;
-    DevBuf &bi = second_set ? ix->w2_idx : ix->w_idx;
-    DevBuf &bc = second_set ? ix->w2_cnt : ix->w_cnt;
-    DevBuf &bt = second_set ? ix->w2_tau : ix->w_tau;
+    const ScanPlan pl = second_tier ? plan_segments(ix->n, 1, cap, ix->opt_segments, 4096, 4096)
+                                    : plan_segments(ix->n, nq_pad / kTileQ, cap, ix->opt_segments, 4096, 4096);
+    DevBuf &bk = second_tier ? ws.w2_keys : ws.w_keys;
+    DevBuf &bi = second_tier ? ws.w2_idx : ws.w_idx;
+    DevBuf &bc = second_tier ? ws.w2_cnt : ws.w_cnt;
+    DevBuf &bt = second_tier ? ws.w2_tau : ws.w_tau;
     const size_t slots = (size_t)pl.nseg * nq_pad * (size_t)cap;
     PNCHK(bk.ensure(slots * sizeof(KeyT)));
     PNCHK(bi.ensure(slots * sizeof(uint32_t)));
@@ -527,31 +725,53 @@ static int run_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, 
     void *lo_key = nullptr;
     uint32_t *lo_idx = nullptr;
     if (kout > kRound) {
-        PNCHK(ix->w_lo.ensure(nq_pad * (sizeof(KeyT) + sizeof(uint32_t))));
-        lo_key = ix->w_lo.p;
-        lo_idx = (uint32_t *)((char *)ix->w_lo.p + nq_pad * sizeof(KeyT));
+        PNCHK(ws.w_lo.ensure(nq_pad * (sizeof(KeyT) + sizeof(uint32_t))));
+        lo_key = ws.w_lo.p;
+        lo_idx = (uint32_t *)((char *)ws.w_lo.p + nq_pad * sizeof(KeyT));
     }
-    const bool prof = hot && ix->profile;
-    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    const bool prof = rec && rec->prof;
+    if (prof) {
+        HIPCHK(hipEventRecord(rec->ev[0], s));
+        rec->hot = true;
+    }
     for (size_t done = 0; done < kout; done += kRound) {
         const size_t kr = kout - done < kRound ? kout - done : kRound;
         HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kr, pl.seg_len, cb,
-                           done ? lo_key : nullptr, done ? lo_idx : nullptr, s));
-        if (prof && done == 0) HIPCHK(hipEventRecord(ix->ev1, s));
-        HIPCHK(Ops<T>::select(cb, (int)nq, (int)kr, ix->index_base, d_idx, d_dist, kout, done, lo_key, lo_idx, s));
-    }
-    if (prof) {
-        HIPCHK(hipEventSynchronize(ix->ev1));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-        ix->stats.hot_ms += ms;
-        ix->stats.hot_launches += 1;
+                           done ? lo_key : nullptr, done ? lo_idx : nullptr, nq_dev, nq_off, s));
+        if (prof && done == 0) HIPCHK(hipEventRecord(rec->ev[1], s));
+        HIPCHK(Ops<T>::select(cb, (int)nq, (int)kr, ix->index_base, d_idx, d_dist, out_stride, done, lo_key, lo_idx,
+                              nq_dev, nq_off, s));
     }
     return PN_OK;
 }
 
-static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
-                    float *d_dist, hipStream_t s);
+// Second tier behind a filter tier: the queries whose exclusions the re-rank could not prove (flags, counted in
+// *d_nflag on the device) are listed, gathered, answered by the exact engine and scattered back -- all of it enqueued
+// unconditionally and driven by the device-side count, so the host never waits to learn whether anything was flagged
+// (with nothing flagged every kernel here exits at once).  Rounds of kSecondTierRows queries bound the scratch.
+constexpr size_t kSecondTierRows = 16384;
+static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kout,
+                             const uint32_t *d_flags, uint32_t *d_nsel, uint64_t *d_idx, float *d_dist,
+                             size_t out_stride, hipStream_t s) {
+    const size_t F = nq < kSecondTierRows ? nq : kSecondTierRows, F_pad = round_up(F, (size_t)256);
+    PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
+    PNCHK(ws.w_gq.ensure(F_pad * ix->ld * sizeof(float)));  // rows beyond the count are never read as queries
+    PNCHK(ws.w_gidx.ensure(F * kout * sizeof(uint64_t)));
+    PNCHK(ws.w_gdist.ensure(F * kout * sizeof(float)));
+    HIPCHK(launch_compact_flags(d_flags, (int)nq, (uint32_t *)ws.w_gsel.p, d_nsel, s));
+    for (size_t off = 0; off < nq; off += F) {
+        const size_t fr = nq - off < F ? nq - off : F;
+        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, d_nsel, (uint32_t)off, (uint32_t)fr,
+                                      (float *)ws.w_gq.p, s));
+        PNCHK(run_exact<float>(ix, ws, (const float *)ws.w_gq.p, fr, F_pad, (int)ix->dim, kout, (uint64_t *)ws.w_gidx.p,
+                               (float *)ws.w_gdist.p, kout, s, true, d_nsel, (uint32_t)off, nullptr));
+        HIPCHK(launch_scatter_results_f32((const uint64_t *)ws.w_gidx.p, (const float *)ws.w_gdist.p,
+                                          (const uint32_t *)ws.w_gsel.p, d_nsel, (uint32_t)off, (uint32_t)fr, (int)kout,
+                                          d_idx, d_dist, out_stride, s));
+    }
+    return PN_OK;
+}
+
 // k' kept by the filter per (segment, query).  The proof in select.hip needs every segment's k'-th
 // lower bound to clear the GLOBAL k-th exact distance; with >= 3 segments per query tile (always the
 // case for the persistent partition when query tiles <= CUs / 3) a segment's k'-th bound is far above
@@ -587,7 +807,7 @@ struct Bf16Plan {
 // then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
 // same rows at the same time, which is what lets them share corpus tiles in L2 (1M x 768, 10^4 queries: 240 aligned
 // workgroups 15.0 ms, 256 balanced ones 15.6 ms).  The kernel itself takes any number of workgroups.
-static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
+static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, int level) {
     Bf16Plan p{};
     p.wide = true;
     p.split = 1;
@@ -624,7 +844,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
         double kp;
         if (ix->filter_slots > 0)
             kp = (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
-        else if (ix->bf16_level != 0)
+        else if (level != 0)
             kp = R + 6.0 * std::sqrt(R) + 4.0;
         else {
             const double per = R / segs;
@@ -632,7 +852,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
             if (kp < 8.0) kp = 8.0;
         }
         p.kp = (int)std::ceil(kp);
-        p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256;
+        p.ok = level < 2 && p.kp + 32 <= 256;
         p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
         // the re-rank kernel gathers all cells of a query into 64 KiB of LDS (12 B per slot + the query row)
         if (best == 1 || (size_t)p.nseg * (size_t)p.cap * 12 + (ix->dim + 8) * 4 <= 60 * 1024) break;
@@ -645,7 +865,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout) {
     // number of the R relevant rows in it (<= 1.2), seed_rank = smallest rank with P(Poisson >= rank) <= 1e-7
     p.shared_scout = false;
 #ifndef PN_DIAG_NO_SHARED_SCOUT
-    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && segs >= 4.0) {
+    if (p.ok && level == 0 && ix->filter_slots == 0 && segs >= 4.0) {
         const size_t run_len = q_tiles * r_tiles / (size_t)p.n_wg;
         double t = 1.2 * (double)ix->n / (R * segs * 128.0);  // tiles per run for lambda = 1.2
         if (t > 16.0) t = 16.0;
@@ -691,8 +911,8 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
     while (c < c_max && eff_of(c) < best_eff - 0.05) ++c;
     return q_tiles * c;
 }
-static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
-    if (bf16_is_wide((int)ix->dim)) return bf16_plan_wide(ix, nq_pad, kout);
+static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int level) {
+    if (bf16_is_wide((int)ix->dim)) return bf16_plan_wide(ix, nq_pad, kout, level);
     Bf16Plan p{};
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
     size_t n_wg = 2 * (size_t)ix->n_cu;
@@ -715,7 +935,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     if (per_tile < 1) per_tile = 1;
     auto kp_for = [&](int split) -> double {
         if (ix->filter_slots > 0) return (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
-        if (ix->bf16_level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
+        if (level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
         const double per = R / (double)(per_tile * (size_t)split);
         const double v = per + 5.0 * std::sqrt(per) + 3.0;  // ~1e-6 per (query, segment) of holding more than that
         return v < 8.0 ? 8.0 : v;
@@ -723,11 +943,11 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     // split the rows of a query tile into parts only while one buffer would need more than 128 slots
     // (every part pays its own warm-up), and keep parts of at least 256 tiles
     p.split = 1;
-    if (ix->bf16_level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0)
+    if (level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0)
         while (p.split < 8 && kp_for(p.split) > 96.0 && r_tiles / (size_t)(2 * p.split) >= 256) p.split *= 2;
     const double kp = kp_for(p.split);
     p.kp = (int)std::ceil(kp);
-    p.ok = ix->bf16_level < 2 && p.kp + 32 <= 256;
+    p.ok = level < 2 && p.kp + 32 <= 256;
     p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
     p.nseg = bf16_segments(q_tiles, p.n_wg, p.split);
     // aligned partition: exactly n_wg / q_tiles segments, every cell written by exactly one workgroup
@@ -743,7 +963,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
     // P(Poisson(lambda) >= rank) <= 1e-7 (a seed that is too low only sends the query to the next tier).
     p.shared_scout = false;
 #ifndef PN_DIAG_NO_SHARED_SCOUT
-    if (p.ok && ix->bf16_level == 0 && ix->filter_slots == 0 && p.split == 1 && per_tile >= 2 &&
+    if (p.ok && level == 0 && ix->filter_slots == 0 && p.split == 1 && per_tile >= 2 &&
         p.n_wg % (int)q_tiles == 0) {
         const size_t run_len = r_tiles / per_tile;
         double t = 1.2 * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup for lambda = 1.2
@@ -766,69 +986,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout) {
 #endif
     return p;
 }
-static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
-                    float *d_dist, hipStream_t s, bool mfma_fallback);
-
-template <typename T>
-static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
-                             uint64_t *d_idx, T *d_dist, hipStream_t s) {
-    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
-    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
-    const size_t kout = k < ix->n ? k : ix->n;
-    if (nq == 0 || kout == 0) return PN_OK;  // k == 0 -> empty result (src/ball_tree.rs:106-108)
-    if (!d_q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
-    if (!d_idx || !d_dist) return fail(PN_ERR_INVALID, "output buffer is NULL");
-    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
-    DeviceGuard g(ix->device);
-    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    // s == NULL is HIP's default stream (what torch.cuda.current_stream() is unless changed): work is
-    // ordered with the caller's other default-stream work, as a caller of a *_device entry point expects
-    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;  // zip truncation (src/distance.rs:27-28)
-    if (ix->profile) {
-        PNCHK(ensure_events(ix));
-        HIPCHK(hipEventRecord(ix->ev2, s));
-    }
-    const size_t chunk = 1u << 18;
-    for (size_t qs = 0; qs < nq; qs += chunk) {
-        const size_t nqc = (nq - qs < chunk) ? nq - qs : chunk;
-        const size_t nq_pad = round_up(nqc, (size_t)256);  // query tiles are 64 (exact), 128 (MFMA) or 256 (bf16) rows
-        PNCHK(ix->w_q.ensure(nq_pad * ix->ld * sizeof(T)));
-        T *Qp = (T *)ix->w_q.p;
-        HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
-        uint64_t *oi = d_idx + qs * kout;
-        T *od = d_dist + qs * kout;
-        bool use_mfma = false, use_bf16 = false;
-        if (sizeof(T) == 4 && ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT) {
-            // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
-            use_mfma = mfma_slots(ix, kout, nq_pad) + 64 <= 256;
-            if (ix->ld > 128 && mfma_slots(ix, kout, nq_pad) > 30) use_mfma = false;  // wide rows: LDS-buffer kernel only
-            if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
-        }
-        if (sizeof(T) == 4 && ix->bf16_ok && dim_eff == ix->dim &&
-            (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8)))
-            use_bf16 = bf16_plan(ix, nq_pad, kout).ok;
-        if (use_bf16)
-            PNCHK(run_bf16(ix, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, s, use_mfma));
-        else if (use_mfma)
-            PNCHK(run_mfma(ix, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, s));
-        else
-            PNCHK(run_exact<T>(ix, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, s, false, true));
-        ix->stats.queries += nqc;
-    }
-    if (ix->profile) {
-        HIPCHK(hipEventRecord(ix->ev3, s));
-        HIPCHK(hipEventSynchronize(ix->ev3));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ix->ev2, ix->ev3));
-        ix->stats.last_call_ms = ms;
-    }
-    return PN_OK;
-}
-
-// MFMA filter -> exact re-rank -> verification -> exact fallback for flagged queries
-static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
-                    float *d_dist, hipStream_t s) {
+// f32 MFMA filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for flagged queries
+static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t nq_pad, size_t kout,
+                    uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s, CallRec *rec) {
     // candidate slots kept per (segment, query)
     const size_t kp = mfma_slots(ix, kout, nq_pad);
     // persistent-partition kernels: k' <= 30 with LDS candidate buffers (structure 2, wide rows), k' <= 224 with
@@ -839,14 +999,10 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     int cap = v2 ? (int)round_up(kp, 32) : pick_cap(kp);
     if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
     // scaled query norms (same kernel as the corpus norms)
-    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
-    PNCHK(ix->w_misc.ensure(64));
-    uint32_t *d_nflag = (uint32_t *)ix->w_misc.p;           // [0] = flagged count, [1] = non-finite query norms
-    uint64_t *d_ncand = (uint64_t *)((char *)ix->w_misc.p + 8);
-    uint32_t *d_nsel = (uint32_t *)((char *)ix->w_misc.p + 16);
-    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
-    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
-                                d_nflag + 1, s));
+    PNCHK(ws.w_qnorm.ensure(nq_pad * sizeof(float)));
+    uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [0] flagged count, [1] non-finite query norms, [4] second-tier list length
+    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ws.w_qnorm.p,
+                                d_misc + 1, s));
     MfmaPlan plan{};
     // structure 3: persistent partition with HBM candidate buffers and two workgroups per CU
     const bool two_per_cu = v2 && hbm_ok;
@@ -869,182 +1025,210 @@ static int run_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pa
     }
     const size_t cells = (size_t)plan.nseg * nq_pad;
     const size_t slots = cells * (size_t)cap;
-    PNCHK(ix->w_keys.ensure(slots * sizeof(uint32_t)));
-    PNCHK(ix->w_idx.ensure(slots * sizeof(uint32_t)));
-    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
-    CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_idx.p, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, plan.nseg, cap};
+    PNCHK(ws.w_keys.ensure(slots * sizeof(uint32_t)));
+    PNCHK(ws.w_idx.ensure(slots * sizeof(uint32_t)));
+    PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_tau.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ws.w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
+    CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_idx.p, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, plan.nseg, cap};
     if (v2) {  // not every (segment, query tile) cell is written by the persistent partition
-        HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+        HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_tau.p, (int)0xFF800000u, cells, s));
     }
-    const bool prof = ix->profile;
-    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
+    const bool prof = rec && rec->prof;
+    if (prof) {
+        HIPCHK(hipEventRecord(rec->ev[0], s));
+        rec->hot = true;
+    }
     uint32_t *gcand = nullptr;
     if (two_per_cu) {
-        PNCHK(ix->w_sel.ensure(mfma_v2_gcand_bytes(n_wg, (int)kp)));
-        gcand = (uint32_t *)ix->w_sel.p;
+        PNCHK(ws.w_sel.ensure(mfma_v2_gcand_bytes(n_wg, (int)kp)));
+        gcand = (uint32_t *)ws.w_sel.p;
     }
     if (v2)
         HIPCHK(launch_mfma_filter_v2_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp,
-                                         (const float *)ix->w_qnorm.p, ix->ld, (int)kp, cb, n_wg, gcand, s));
+                                         (const float *)ws.w_qnorm.p, ix->ld, (int)kp, cb, n_wg, gcand, s));
     else
         HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld,
-                                      Qp, (const float *)ix->w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
-    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
+                                      Qp, (const float *)ws.w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
+    if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
-                                    (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_flags.p, d_nflag,
-                                    d_ncand, nullptr, nullptr, (uint32_t *)ix->w_qstat.p, s));
-    struct { uint32_t nflag, qnonfinite; uint64_t ncand; uint64_t pad[2]; uint64_t neval; } h{};
-    HIPCHK(hipMemcpyAsync(&h, ix->w_misc.p, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (prof) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-        ix->stats.hot_ms += ms;
-        ix->stats.hot_launches += 1;
-    }
-    ix->stats.candidates += h.ncand;
-    ix->stats.evaluations += h.neval;
-    if (h.nflag) {
-        // re-run the unproven queries on the exact engine
-        const size_t nf = h.nflag;
-        const size_t nf_pad = round_up(nf, (size_t)128);
-        PNCHK(ix->w_sel.ensure(nq * sizeof(uint32_t)));
-        PNCHK(ix->w_fq.ensure(nf_pad * ix->ld * sizeof(float)));
-        PNCHK(ix->w_fidx.ensure(nf * kout * sizeof(uint64_t)));
-        PNCHK(ix->w_fdist.ensure(nf * kout * sizeof(float)));
-        HIPCHK(hipMemsetAsync(ix->w_fq.p, 0, nf_pad * ix->ld * sizeof(float), s));
-        HIPCHK(launch_compact_flags((const uint32_t *)ix->w_flags.p, (int)nq, (uint32_t *)ix->w_sel.p, d_nsel, s));
-        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_sel.p, (int)nf, (float *)ix->w_fq.p, s));
-        PNCHK(run_exact<float>(ix, (const float *)ix->w_fq.p, nf, nf_pad, (int)ix->dim, kout, (uint64_t *)ix->w_fidx.p,
-                               (float *)ix->w_fdist.p, s, true, false));
-        HIPCHK(launch_scatter_results_f32((const uint64_t *)ix->w_fidx.p, (const float *)ix->w_fdist.p,
-                                          (const uint32_t *)ix->w_sel.p, (int)nf, (int)kout, d_idx, d_dist, s));
-        ix->stats.fallback_queries += nf;
-    }
+                                    (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,
+                                    d_misc, nullptr, nullptr, (uint32_t *)ws.w_qstat.p, ix->d_stats, s));
     return PN_OK;
 }
 
-// bf16 filter -> exact re-rank -> verification -> f32 MFMA engine (or exact scan) for the unproven queries
-static int run_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, size_t kout, uint64_t *d_idx,
-                    float *d_dist, hipStream_t s, bool mfma_fallback) {
-    const Bf16Plan plan = bf16_plan(ix, nq_pad, kout);
+// bf16 filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for the unproven queries
+static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, const float *Qp, size_t nq, size_t nq_pad,
+                    size_t kout, uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s, CallRec *rec) {
     if (!plan.ok) return fail(PN_ERR_UNSUPPORTED, "bf16 tier cannot serve k = %zu", kout);
     const int n_wg = plan.n_wg, cap = plan.cap, nseg = plan.nseg;
     const size_t kp = (size_t)plan.kp;
     const size_t cells = (size_t)nseg * nq_pad, slots = cells * (size_t)cap;
-    PNCHK(ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
-    PNCHK(ix->w_qn.ensure(nq_pad * sizeof(double)));
-    PNCHK(ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_keys.ensure(slots * 2 * sizeof(uint32_t)));  // (key, row) pairs
-    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_bflags.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
-    PNCHK(ix->w_bmisc.ensure(64));
-    uint32_t *d_nflag = (uint32_t *)ix->w_bmisc.p;
-    uint64_t *d_ncand = (uint64_t *)((char *)ix->w_bmisc.p + 8);
-    uint32_t *d_nsel = (uint32_t *)((char *)ix->w_bmisc.p + 16);
-    HIPCHK(hipMemsetAsync(ix->w_bmisc.p, 0, 64, s));
-    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
-                                    (uint32_t *)ix->w_qbad.p, s));
-    CandBuf cb{ix->w_keys.p, (uint32_t *)ix->w_keys.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
+    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ws.w_qn.ensure(nq_pad * sizeof(double)));
+    PNCHK(ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ws.w_keys.ensure(slots * 2 * sizeof(uint32_t)));  // (key, row) pairs
+    PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_tau.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ws.w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
+    uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
+    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
+                                    (uint32_t *)ws.w_qbad.p, s));
+    CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_keys.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
     if (!plan.aligned) {  // cells without a writer must read "empty" (an aligned partition writes every cell)
-        HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_tau.p, (int)0xFF800000u, cells, s));
+        HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_tau.p, (int)0xFF800000u, cells, s));
     }
-    const bool prof = ix->profile;
-    if (prof) HIPCHK(hipEventRecord(ix->ev0, s));
-    if (plan.wide && plan.shared_scout) {
+    const bool prof = rec && rec->prof;
+    if (prof) {
+        HIPCHK(hipEventRecord(rec->ev[0], s));
+        rec->hot = true;
+        rec->two_launches = plan.shared_scout;  // the dominant kernel runs twice per call: both launches are timed
+    }
+    if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
-        PNCHK(ix->w_lists.ensure(words * sizeof(float)));
-        PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
+        PNCHK(ws.w_lists.ensure(words * sizeof(float)));
+        PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
         if (!plan.aligned)
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg,
-                                       plan.scout_tiles, nullptr, false, (float *)ix->w_lists.p, s));
-        if (prof) HIPCHK(hipEventRecord(ix->ev4, s));
-        HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
-        if (prof) HIPCHK(hipEventRecord(ix->ev5, s));
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg, 0,
-                                       (const uint32_t *)ix->w_seed.p, false, nullptr, s));
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
+        if (plan.wide)
+            HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg,
+                                           plan.scout_tiles, nullptr, false, (float *)ws.w_lists.p, s));
+        else
+            HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
+                                      nullptr, false, (float *)ws.w_lists.p, s));
+        if (prof) HIPCHK(hipEventRecord(rec->ev[4], s));
+        HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s));
+        if (prof) HIPCHK(hipEventRecord(rec->ev[5], s));
+        if (plan.wide)
+            HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg, 0,
+                                           (const uint32_t *)ws.w_seed.p, false, nullptr, s));
+        else
+            HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, 0,
+                                      (const uint32_t *)ws.w_seed.p, false, nullptr, s));
     } else if (plan.wide) {
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, plan.n_wg,
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg,
                                        plan.scout_max, nullptr, false, nullptr, s));
-    } else if (plan.shared_scout) {
-        const size_t words = cells * 2 * (size_t)bf16_scout_list();
-        PNCHK(ix->w_lists.ensure(words * sizeof(float)));
-        PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
-        if (!plan.aligned)
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ix->w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
-        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
-                                  nullptr, false, (float *)ix->w_lists.p, s));
-        if (prof) HIPCHK(hipEventRecord(ix->ev4, s));  // the dominant kernel runs twice per call: both are timed
-        HIPCHK(launch_bf16_seed((const float *)ix->w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ix->w_seed.p, s));
-        if (prof) HIPCHK(hipEventRecord(ix->ev5, s));
-        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, 1, 0,
-                                  (const uint32_t *)ix->w_seed.p, false, nullptr, s));
     } else {
-        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, (int)kp, cb, n_wg, plan.split,
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, plan.split,
                                   plan.scout_max, nullptr, false, nullptr, s));
     }
-    if (prof) HIPCHK(hipEventRecord(ix->ev1, s));
+    if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
-                                    (int)kout, ix->index_base, d_idx, d_dist, (uint32_t *)ix->w_bflags.p, d_nflag,
-                                    d_ncand, (const double *)ix->w_qn.p, (const uint32_t *)ix->w_qbad.p,
-                                    (uint32_t *)ix->w_qstat.p, s));
-    struct { uint32_t nflag, pad; uint64_t ncand; uint64_t pad2[2]; uint64_t neval; } h{};
-    HIPCHK(hipMemcpyAsync(&h, ix->w_bmisc.p, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (prof) {
-        float ms = 0;
-        if (plan.shared_scout) {  // scout launch ev0..ev4, main launch ev5..ev1 (the seed kernel in between is not counted)
-            float a = 0, b = 0;
-            HIPCHK(hipEventElapsedTime(&a, ix->ev0, ix->ev4));
-            HIPCHK(hipEventElapsedTime(&b, ix->ev5, ix->ev1));
-            ms = a + b;
-            ix->stats.hot_launches += 2;
-        } else {
-            HIPCHK(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-            ix->stats.hot_launches += 1;
-        }
-        ix->stats.hot_ms += ms;
+                                    (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,
+                                    d_misc, (const double *)ws.w_qn.p, (const uint32_t *)ws.w_qbad.p,
+                                    (uint32_t *)ws.w_qstat.p, ix->d_stats, s));
+    return PN_OK;
+}
+
+// One k-NN call on queries resident in HBM, everything enqueued on `s`, nothing read back: tier 1 (bf16 filter, f32
+// MFMA filter or the exact engine itself) then, behind a filter tier, the device-driven second tier.  Results of
+// query q at d_idx/d_dist[q * out_stride + r].
+template <typename T>
+static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                         size_t kout, uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s) {
+    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;  // zip truncation (src/distance.rs:27-28)
+    int level;
+    uint64_t call_id;
+    {
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        recs_collect(ix, false);  // finished earlier calls: statistics, and whether the bf16 plan must widen
+        level = ix->sh.bf16_level;
+        call_id = ix->sh.next_call++;
+        ix->sh.stats.queries += nq;
     }
-    ix->stats.candidates += h.ncand;
-    ix->stats.evaluations += h.neval;
-    if (h.nflag) {
-        // second tier for the unproven queries: the f32 MFMA filter (which has its own exact fallback)
-        const size_t nf = h.nflag;
-        const size_t nf_pad = round_up(nf, (size_t)256);
-        PNCHK(ix->w_gsel.ensure(nq * sizeof(uint32_t)));
-        PNCHK(ix->w_gq.ensure(nf_pad * ix->ld * sizeof(float)));
-        PNCHK(ix->w_gidx.ensure(nf * kout * sizeof(uint64_t)));
-        PNCHK(ix->w_gdist.ensure(nf * kout * sizeof(float)));
-        HIPCHK(hipMemsetAsync(ix->w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s));
-        HIPCHK(launch_compact_flags((const uint32_t *)ix->w_bflags.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_nsel, s));
-        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_gsel.p, (int)nf, (float *)ix->w_gq.p, s));
-        const bool prof_saved = ix->profile;
-        const_cast<pn_index *>(ix)->profile = 0;  // hot-kernel statistics describe the first tier only
-        int rc;
-        if (mfma_fallback)
-            rc = run_mfma(ix, (const float *)ix->w_gq.p, nf, nf_pad, kout, (uint64_t *)ix->w_gidx.p,
-                          (float *)ix->w_gdist.p, s);
-        else
-            rc = run_exact<float>(ix, (const float *)ix->w_gq.p, nf, nf_pad, (int)ix->dim, kout,
-                                  (uint64_t *)ix->w_gidx.p, (float *)ix->w_gdist.p, s, true, false);
-        const_cast<pn_index *>(ix)->profile = prof_saved;
-        if (rc != PN_OK) return rc;
-        HIPCHK(launch_scatter_results_f32((const uint64_t *)ix->w_gidx.p, (const float *)ix->w_gdist.p,
-                                          (const uint32_t *)ix->w_gsel.p, (int)nf, (int)kout, d_idx, d_dist, s));
-        ix->stats.fallback_queries += nf;
-        if (nf * 16 > nq && nq >= 64 && ix->filter_slots == 0 && ix->bf16_level < 2)
-            const_cast<pn_index *>(ix)->bf16_level += 1;  // this corpus defeats the current plan: widen it / turn the tier off
+    const size_t chunk = 1u << 18;
+    for (size_t qs = 0; qs < nq; qs += chunk) {
+        const size_t nqc = (nq - qs < chunk) ? nq - qs : chunk;
+        const size_t nq_pad = round_up(nqc, (size_t)256);  // query tiles are 64 (exact), 128 (MFMA) or 256 (bf16) rows
+        CallRec *rec = nullptr;
+        PNCHK(rec_begin(ix, call_id, nqc, &rec));
+        if (rec->prof) HIPCHK(hipEventRecord(rec->ev[2], s));
+        PNCHK(ws.w_q.ensure(nq_pad * ix->ld * sizeof(T)));
+        T *Qp = (T *)ws.w_q.p;
+        HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
+        uint64_t *oi = d_idx + qs * out_stride;
+        T *od = d_dist + qs * out_stride;
+        bool use_mfma = false, use_bf16 = false;
+        Bf16Plan bplan{};
+        if constexpr (sizeof(T) == 4) {
+            if (ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && ix->engine != PN_ENGINE_BF16) {
+                // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
+                use_mfma = mfma_slots(ix, kout, nq_pad) + 64 <= 256;
+                if (ix->ld > 128 && mfma_slots(ix, kout, nq_pad) > 30) use_mfma = false;  // wide rows: LDS-buffer kernel only
+                if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
+            }
+            if (ix->bf16_ok && dim_eff == ix->dim &&
+                (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
+                bplan = bf16_plan(ix, nq_pad, kout, level);
+                use_bf16 = bplan.ok;
+            }
+            if (use_bf16 || use_mfma) {
+                PNCHK(ws.w_misc.ensure(64));
+                HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
+                uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
+                if (use_bf16)
+                    PNCHK(run_bf16(ix, ws, bplan, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
+                else
+                    PNCHK(run_mfma(ix, ws, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
+                PNCHK(second_tier_exact(ix, ws, (const float *)Qp, nqc, kout, (const uint32_t *)ws.w_flags.p, d_misc + 4, oi,
+                                        (float *)od, out_stride, s));
+                // the flagged count travels to pinned memory behind everything else; a LATER call looks at it
+                HIPCHK(hipMemcpyAsync(rec->h_nflag, d_misc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                rec->has_flag = true;
+                rec->bf16_tier = use_bf16;
+            }
+        }
+        if (!use_bf16 && !use_mfma)
+            PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec));
+        if (rec->prof) HIPCHK(hipEventRecord(rec->ev[3], s));
+        PNCHK(rec_end(ix, rec, s));
     }
     return PN_OK;
 }
+
+template <typename T>
+static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, T *d_dist, hipStream_t s) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const size_t kout = k < ix->n ? k : ix->n;
+    if (nq == 0 || kout == 0) return PN_OK;  // k == 0 -> empty result (src/ball_tree.rs:106-108)
+    if (!d_q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
+    if (!d_idx || !d_dist) return fail(PN_ERR_INVALID, "output buffer is NULL");
+    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    // s == NULL is HIP's default stream (what torch.cuda.current_stream() is unless changed): work is
+    // ordered with the caller's other default-stream work, as a caller of a *_device entry point expects
+    WsLease lease(ix);
+    lease.s = s;
+    PNCHK(ws_acquire(ix, &lease.s, false, &lease.ws));
+    return query_enqueue<T>(ix, *lease.ws, d_q, nq, q_cols, q_stride, kout, d_idx, d_dist, kout, s);
+}
+
+namespace pn {
+// pn_query_device_f32 with a row stride on the outputs (results of query q at [q * out_stride + r], r < min(k, n)):
+// a shard writes straight into the packed buffer the all-gather sends (sharded.hip)
+int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    if (ix->elem_bytes != 4) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const size_t kout = k < ix->n ? k : ix->n;
+    if (nq == 0 || kout == 0) return PN_OK;
+    if ((!d_q && q_cols) || !d_idx || !d_dist || out_stride < kout) return fail(PN_ERR_INVALID, "bad argument");
+    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+    WsLease lease(ix);
+    lease.s = s;
+    PNCHK(ws_acquire(ix, &lease.s, false, &lease.ws));
+    return query_enqueue<float>(ix, *lease.ws, d_q, nq, q_cols, q_stride, kout, d_idx, d_dist, out_stride, s);
+}
+}  // namespace pn
 
 extern "C" int pn_query_device_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
                                    size_t k, uint64_t *d_idx, float *d_dist, void *stream) {
@@ -1055,7 +1239,25 @@ extern "C" int pn_query_device_f64(const pn_index *ix, const double *d_q, size_t
     return query_device_impl<double>(ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, (hipStream_t)stream);
 }
 
-// host staging: queries H2D, results D2H
+// host staging into a pooled buffer: rows [rows][cols] contiguous on the device
+template <typename T>
+static int upload_rows_to(const T *h, size_t rows, size_t cols, ptrdiff_t row_stride, DevBuf &buf, hipStream_t s) {
+    const size_t c = cols ? cols : 1;
+    PNCHK(buf.ensure(rows * c * sizeof(T)));
+    if (cols == 0) return PN_OK;
+    if (row_stride < 0) return fail(PN_ERR_UNSUPPORTED, "negative row stride");
+    T *d = (T *)buf.p;
+    if (rows == 1 || (size_t)row_stride == cols)
+        HIPCHK(hipMemcpyAsync(d, h, rows * cols * sizeof(T), hipMemcpyHostToDevice, s));
+    else if (row_stride == 0) {
+        for (size_t r = 0; r < rows; ++r)
+            HIPCHK(hipMemcpyAsync(d + r * cols, h, cols * sizeof(T), hipMemcpyHostToDevice, s));
+    } else
+        HIPCHK(hipMemcpy2DAsync(d, cols * sizeof(T), h, (size_t)row_stride * sizeof(T), cols * sizeof(T), rows,
+                                hipMemcpyHostToDevice, s));
+    return PN_OK;
+}
+// one-off staging (diagnostics, pairwise): own allocation
 template <typename T>
 static int upload_rows(const T *h, size_t rows, size_t cols, ptrdiff_t row_stride, T **d_out) {
     *d_out = nullptr;
@@ -1074,6 +1276,9 @@ static int upload_rows(const T *h, size_t rows, size_t cols, ptrdiff_t row_strid
     return PN_OK;
 }
 
+// Host entry point: what the reference's one-point-per-call API maps to (src/ball_tree.rs:102; nq = 1 is that call).
+// Staging buffers come from the workspace (no allocation per call once warm); the call runs on the workspace's own
+// stream, so host threads sharing one handle do not serialise each other.
 template <typename T>
 static int query_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, size_t k,
                            uint64_t *idx_out, T *dist_out) {
@@ -1083,31 +1288,22 @@ static int query_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_c
     if (nq == 0 || kout == 0) return PN_OK;
     if (!q && q_cols) return fail(PN_ERR_INVALID, "queries is NULL");
     if (!idx_out || !dist_out) return fail(PN_ERR_INVALID, "output buffer is NULL");
+    if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
-    T *d_q = nullptr, *d_dist = nullptr;
-    uint64_t *d_idx = nullptr;
-    int rc = upload_rows<T>(q, nq, q_cols, q_stride, &d_q);
-    do {
-        if (rc != PN_OK) break;
-        if (hipMalloc((void **)&d_idx, nq * kout * sizeof(uint64_t)) != hipSuccess ||
-            hipMalloc((void **)&d_dist, nq * kout * sizeof(T)) != hipSuccess) {
-            rc = fail(PN_ERR_NOMEM, "hipMalloc results failed");
-            break;
-        }
-        rc = query_device_impl<T>(ix, d_q, nq, q_cols, q_cols ? q_cols : 1, k, d_idx, d_dist, ix->stream);
-        if (rc != PN_OK) break;
-        if (hipStreamSynchronize(ix->stream) != hipSuccess ||
-            hipMemcpy(idx_out, d_idx, nq * kout * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(dist_out, d_dist, nq * kout * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
-            rc = fail(PN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-    } while (0);
-    if (d_q) (void)hipFree(d_q);
-    if (d_idx) (void)hipFree(d_idx);
-    if (d_dist) (void)hipFree(d_dist);
-    return rc;
+    WsLease lease(ix);
+    PNCHK(ws_acquire(ix, &lease.s, true, &lease.ws));
+    Workspace &ws = *lease.ws;
+    hipStream_t s = lease.s;
+    PNCHK(upload_rows_to<T>(q, nq, q_cols, q_stride, ws.w_hq, s));
+    PNCHK(ws.w_hidx.ensure(nq * kout * sizeof(uint64_t)));
+    PNCHK(ws.w_hdist.ensure(nq * kout * sizeof(T)));
+    PNCHK(query_enqueue<T>(ix, ws, (const T *)ws.w_hq.p, nq, q_cols, q_cols ? q_cols : 1, kout, (uint64_t *)ws.w_hidx.p,
+                           (T *)ws.w_hdist.p, kout, s));
+    HIPCHK(hipMemcpyAsync(idx_out, ws.w_hidx.p, nq * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(dist_out, ws.w_hdist.p, nq * kout * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PN_OK;
 }
 
 extern "C" int pn_query_f32(const pn_index *ix, const float *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, size_t k,
@@ -1138,30 +1334,32 @@ extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq,
     if (nq * n_rows > ((size_t)1 << 28)) return fail(PN_ERR_INVALID, "too many bounds requested");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    hipStream_t s = ix->stream;
+    WsLease lease(ix);
+    PNCHK(ws_acquire(ix, &lease.s, true, &lease.ws));
+    Workspace &ws = *lease.ws;
+    hipStream_t s = lease.s;
     float *d_q = nullptr, *d_out = nullptr;
     int rc = upload_rows<float>(q, nq, q_cols, q_stride, &d_q);
     do {
         if (rc != PN_OK) break;
         const size_t nq_pad = round_up(nq, (size_t)256);
         rc = PN_ERR_DEVICE;
-        if (ix->w_q.ensure(nq_pad * ix->ld * sizeof(float)) != PN_OK ||
-            ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)) != PN_OK ||
-            ix->w_qn.ensure(nq_pad * sizeof(double)) != PN_OK || ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)) != PN_OK)
+        if (ws.w_q.ensure(nq_pad * ix->ld * sizeof(float)) != PN_OK ||
+            ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)) != PN_OK ||
+            ws.w_qn.ensure(nq_pad * sizeof(double)) != PN_OK || ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)) != PN_OK)
             break;
         if (hipMalloc((void **)&d_out, nq * n_rows * sizeof(float)) != hipSuccess) {
             rc = fail(PN_ERR_NOMEM, "hipMalloc bounds failed");
             break;
         }
-        float *Qp = (float *)ix->w_q.p;
+        float *Qp = (float *)ws.w_q.p;
         if (launch_pack_rows_f32(d_q, nq, ix->dim, q_cols, Qp, nq_pad, ix->ld, s) != hipSuccess ||
-            launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
-                                     (uint32_t *)ix->w_qbad.p, s) != hipSuccess ||
-            launch_bf16_bound(ix->d_img, ix->w_bq.p, n_rows, nq, (int)ix->dim, d_out, s) != hipSuccess ||
+            launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
+                                     (uint32_t *)ws.w_qbad.p, s) != hipSuccess ||
+            launch_bf16_bound(ix->d_img, ws.w_bq.p, n_rows, nq, (int)ix->dim, d_out, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess ||
             hipMemcpy(bounds_out, d_out, nq * n_rows * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-            (qnorm_out && hipMemcpy(qnorm_out, ix->w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) ||
+            (qnorm_out && hipMemcpy(qnorm_out, ws.w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) ||
             (mu_out && hipMemcpy(mu_out, ix->d_mu, ix->dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
             rc = fail(PN_ERR_DEVICE, "bf16 bounds failed: %s", hipGetErrorString(hipGetLastError()));
             break;
@@ -1198,7 +1396,7 @@ template <> struct RadOps<double> {
 // exact radius queries: count pass -> host exclusive scan -> fill pass (exact scan kernel); offs gets nq + 1
 // entries, *out a malloc'ed array of offs[nq] global row numbers, ascending per query
 template <typename T>
-static int radius_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pad, size_t dim_eff, T radius,
+static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t nq_pad, size_t dim_eff, T radius,
                         std::vector<uint64_t> &offs, uint64_t **out, hipStream_t s) {
     *out = nullptr;
     uint32_t *d_counts = nullptr;
@@ -1236,7 +1434,10 @@ static int radius_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pa
             }
         }
         offs[nq] = run;
-        ix->stats.radius_results += run;
+        {
+            std::lock_guard<std::mutex> lk(ix->sh.mu);
+            ix->sh.stats.radius_results += run;
+        }
         uint64_t *h_out = (uint64_t *)malloc((run ? run : 1) * sizeof(uint64_t));
         if (!h_out) { rc = fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)run); break; }
         *out = h_out;
@@ -1259,13 +1460,13 @@ static int radius_exact(const pn_index *ix, const T *Qp, size_t nq, size_t nq_pa
 }
 
 // common tail of the filtered radius paths: kept rows per query (w_keys, ascending) -> CSR on the host
-static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
+static int radius_finish(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
                          const uint32_t *d_over, float radius, uint64_t *offsets, uint64_t **idx_out, bool *done,
                          hipStream_t s) {
     uint32_t h_misc[2] = {0, 0};
     std::vector<uint32_t> h_n(nq);
     HIPCHK(hipMemcpyAsync(h_misc, d_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_n.data(), ix->w_flags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_n.data(), ws.w_flags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (h_misc[1]) return PN_OK;                        // queries the filter cannot serve: next tier
     if (h_misc[0] && (!d_over || h_misc[0] * 4 > nq)) return PN_OK;  // many overflowed lists: next tier for the call
@@ -1279,7 +1480,7 @@ static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t 
                 sel.push_back((uint32_t)a);
                 h_n[a] = 0;
             }
-        HIPCHK(hipMemcpyAsync(ix->w_flags.p, h_n.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(ws.w_flags.p, h_n.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     }
     std::vector<uint64_t> h_off(nq + 1);
     uint64_t run = 0;
@@ -1297,7 +1498,7 @@ static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t 
             rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed");
         if (rc == PN_OK &&
             (hipMemcpyAsync(d_off, h_off.data(), (nq + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
-             launch_radius_gather((const uint32_t *)ix->w_keys.p, (const uint32_t *)ix->w_flags.p, d_off, (int)nq,
+             launch_radius_gather((const uint32_t *)ws.w_keys.p, (const uint32_t *)ws.w_flags.p, d_off, (int)nq,
                                   kept_stride, ix->index_base, d_out, s) != hipSuccess ||
              hipMemcpyAsync(h_out, d_out, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
              hipStreamSynchronize(s) != hipSuccess))
@@ -1309,19 +1510,25 @@ static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t 
             return rc;
         }
     }
-    ix->stats.radius_results += run;
+    {
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        ix->sh.stats.radius_results += run;
+    }
     if (!sel.empty()) {
         const size_t nf = sel.size(), nf_pad = round_up(nf, (size_t)256);
         std::vector<uint64_t> offs_x;
         uint64_t *out_x = nullptr;
         int rc = PN_OK;
-        if (ix->w_gsel.ensure(nf * sizeof(uint32_t)) != PN_OK || ix->w_gq.ensure(nf_pad * ix->ld * sizeof(float)) != PN_OK ||
-            hipMemsetAsync(ix->w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s) != hipSuccess ||
-            hipMemcpyAsync(ix->w_gsel.p, sel.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
-            launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ix->w_gsel.p, (int)nf, (float *)ix->w_gq.p, s) != hipSuccess)
+        sel.push_back((uint32_t)nf);  // the gather kernel reads its row count from the device: kept behind the list
+        if (ws.w_gsel.ensure((nf + 1) * sizeof(uint32_t)) != PN_OK || ws.w_gq.ensure(nf_pad * ix->ld * sizeof(float)) != PN_OK ||
+            hipMemsetAsync(ws.w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s) != hipSuccess ||
+            hipMemcpyAsync(ws.w_gsel.p, sel.data(), (nf + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+            launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, (const uint32_t *)ws.w_gsel.p + nf, 0,
+                                   (uint32_t)nf, (float *)ws.w_gq.p, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)  // `sel` is pageable host memory: the copy must have left it
             rc = fail(PN_ERR_DEVICE, "radius fallback staging failed: %s", hipGetErrorString(hipGetLastError()));
         if (rc == PN_OK)
-            rc = radius_exact<float>(ix, (const float *)ix->w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
+            rc = radius_exact<float>(ix, ws, (const float *)ws.w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
         if (rc != PN_OK) {
             free(h_out);
             return rc;
@@ -1353,7 +1560,10 @@ static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t 
         free(h_out);
         free(out_x);
         *idx_out = h_all;
-        ix->stats.fallback_queries += nf;
+        {
+            std::lock_guard<std::mutex> lk(ix->sh.mu);
+            ix->sh.stats.fallback_queries += nf;
+        }
         *done = true;
         return PN_OK;
     }
@@ -1364,7 +1574,7 @@ static int radius_finish(const pn_index *ix, const float *Qp, size_t nq, size_t 
 }
 
 // first tier for radius queries: the bf16 filter against each query's fixed bound, exact check of the survivors
-static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
                        uint64_t **idx_out, bool *done, hipStream_t s) {
     *done = false;
     const int cap = 256;  // up to 224 rows within the radius per (segment, query) before the call overflows
@@ -1379,7 +1589,7 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     const bool wide = bf16_is_wide((int)ix->dim);
     int wide_wg = 1;
     if (wide) {  // the k-NN plan's partition, at most 32 segments per query (the check kernel's LDS budget)
-        wide_wg = bf16_plan_wide(ix, nq_pad, 1).n_wg;
+        wide_wg = bf16_plan_wide(ix, nq_pad, 1, level).n_wg;
         while (wide_wg > 1 && bf16_wide_segments(q_tiles, wide_wg) > 32) wide_wg = (wide_wg + 1) / 2;
     }
     const int nseg = wide ? bf16_wide_segments(q_tiles, wide_wg) : bf16_segments(q_tiles, (int)n_wg, 1);
@@ -1389,41 +1599,41 @@ static int radius_bf16(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     // below it (same allowances as the k-NN proof)
     const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
     if (!(t < 1e37)) return PN_OK;  // let the exact engine decide
-    PNCHK(ix->w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
-    PNCHK(ix->w_qn.ensure(nq_pad * sizeof(double)));
-    PNCHK(ix->w_qbad.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_seed.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ix->w_misc.ensure(64));
-    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_tau.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_idx.ensure(cells * cap * 2 * sizeof(uint32_t)));      // (key, row) pairs
-    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));    // kept rows per query
-    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));             // kept counts
-    PNCHK(ix->w_bflags.ensure(nq_pad * sizeof(uint32_t)));            // per-query overflow flags
-    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
-    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
-    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ix->w_bq.p, (double *)ix->w_qn.p,
-                                    (uint32_t *)ix->w_qbad.p, s));
-    PNCHK(ix->w_gsel.ensure(nq * sizeof(uint32_t)));
-    HIPCHK(launch_compact_flags((const uint32_t *)ix->w_qbad.p, (int)nq, (uint32_t *)ix->w_gsel.p, d_misc + 1, s));
-    HIPCHK(launch_bf16_radius_tau((const double *)ix->w_qn.p, nq_pad, t, (uint32_t *)ix->w_seed.p, s));
-    CandBuf cb{ix->w_idx.p, (uint32_t *)ix->w_idx.p + 1, (uint32_t *)ix->w_cnt.p, ix->w_tau.p, nq_pad, nseg, cap, 2};
+    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ws.w_qn.ensure(nq_pad * sizeof(double)));
+    PNCHK(ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
+    PNCHK(ws.w_misc.ensure(64));
+    PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_tau.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_idx.ensure(cells * cap * 2 * sizeof(uint32_t)));      // (key, row) pairs
+    PNCHK(ws.w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));    // kept rows per query
+    PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));             // kept counts
+    PNCHK(ws.w_sel.ensure(nq_pad * sizeof(uint32_t)));            // per-query overflow flags
+    uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
+    HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
+                                    (uint32_t *)ws.w_qbad.p, s));
+    PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
+    HIPCHK(launch_compact_flags((const uint32_t *)ws.w_qbad.p, (int)nq, (uint32_t *)ws.w_gsel.p, d_misc + 1, s));
+    HIPCHK(launch_bf16_radius_tau((const double *)ws.w_qn.p, nq_pad, t, (uint32_t *)ws.w_seed.p, s));
+    CandBuf cb{ws.w_idx.p, (uint32_t *)ws.w_idx.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
     if (wide)
-        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, wide_wg, 0,
-                                       (const uint32_t *)ix->w_seed.p, true, nullptr, s));
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, wide_wg, 0,
+                                       (const uint32_t *)ws.w_seed.p, true, nullptr, s));
     else
-        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ix->w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
-                                  (const uint32_t *)ix->w_seed.p, true, nullptr, s));
-    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p + 1, nq_pad, nseg, cap,
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
+                                  (const uint32_t *)ws.w_seed.p, true, nullptr, s));
+    HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 2,
-                                   (uint32_t *)ix->w_bflags.p, s));
-    return radius_finish(ix, Qp, nq, kept_stride, d_misc, (const uint32_t *)ix->w_bflags.p, radius, offsets, idx_out, done,
+                                   (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
+                                   (uint32_t *)ws.w_sel.p, s));
+    return radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets, idx_out, done,
                          s);
 }
 
-static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+static int radius_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
                        uint64_t **idx_out, bool *done, hipStream_t s) {
     *done = false;
     const uint32_t cap = 32;
@@ -1444,23 +1654,23 @@ static int radius_mfma(const pn_index *ix, const float *Qp, size_t nq, size_t nq
     if (!(tf < INFINITY)) return PN_OK;  // r^2 overflows f32: let the exact engine decide
     const float tau_excl = nextafterf(tf, INFINITY);
 
-    PNCHK(ix->w_qnorm.ensure(nq_pad * sizeof(float)));
-    PNCHK(ix->w_misc.ensure(64));
-    PNCHK(ix->w_cnt.ensure(cells * sizeof(uint32_t)));
-    PNCHK(ix->w_idx.ensure(cells * cap * sizeof(uint32_t)));
-    PNCHK(ix->w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));  // kept rows per query
-    PNCHK(ix->w_flags.ensure(nq_pad * sizeof(uint32_t)));           // kept counts
-    uint32_t *d_misc = (uint32_t *)ix->w_misc.p;  // [0] overflow count, [1] non-finite query norms
-    HIPCHK(hipMemsetAsync(ix->w_misc.p, 0, 64, s));
-    HIPCHK(hipMemsetAsync(ix->w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ix->w_qnorm.p,
+    PNCHK(ws.w_qnorm.ensure(nq_pad * sizeof(float)));
+    PNCHK(ws.w_misc.ensure(64));
+    PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
+    PNCHK(ws.w_idx.ensure(cells * cap * sizeof(uint32_t)));
+    PNCHK(ws.w_keys.ensure(nq * kept_stride * sizeof(uint32_t)));  // kept rows per query
+    PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));           // kept counts
+    uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [0] overflow count, [1] non-finite query norms
+    HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ws.w_qnorm.p,
                                 d_misc + 1, s));
-    HIPCHK(launch_mfma_radius_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ix->w_qnorm.p,
-                                  nq_pad, tau_excl, cap, (uint32_t *)ix->w_cnt.p, (uint32_t *)ix->w_idx.p, (int)n_wg, s));
-    HIPCHK(launch_radius_check_f32((const uint32_t *)ix->w_cnt.p, (const uint32_t *)ix->w_idx.p, nq_pad, nseg, cap,
+    HIPCHK(launch_mfma_radius_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ws.w_qnorm.p,
+                                  nq_pad, tau_excl, cap, (uint32_t *)ws.w_cnt.p, (uint32_t *)ws.w_idx.p, (int)n_wg, s));
+    HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ix->w_keys.p, (uint32_t *)ix->w_flags.p, d_misc, 1, nullptr, s));
-    return radius_finish(ix, Qp, nq, kept_stride, d_misc, nullptr, radius, offsets, idx_out, done, s);
+                                   (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 1, nullptr, s));
+    return radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, nullptr, radius, offsets, idx_out, done, s);
 }
 
 template <typename T>
@@ -1476,44 +1686,51 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
     if (nq > 0x7FFFFFFFull) return fail(PN_ERR_UNSUPPORTED, "too many queries in one call");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    hipStream_t s = ix->stream;
+    WsLease lease(ix);
+    PNCHK(ws_acquire(ix, &lease.s, true, &lease.ws));
+    Workspace &ws = *lease.ws;
+    hipStream_t s = lease.s;
+    int level;
+    {
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        recs_collect(ix, false);
+        level = ix->sh.bf16_level;
+    }
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
     const size_t nq_pad = round_up(nq, (size_t)256);
-    T *d_q = nullptr;
-    int rc = upload_rows<T>(q, nq, q_cols, q_stride, &d_q);
+    int rc = upload_rows_to<T>(q, nq, q_cols, q_stride, ws.w_hq, s);
     do {
         if (rc != PN_OK) break;
-        rc = ix->w_q.ensure(nq_pad * ix->ld * sizeof(T));
+        rc = ws.w_q.ensure(nq_pad * ix->ld * sizeof(T));
         if (rc != PN_OK) break;
-        T *Qp = (T *)ix->w_q.p;
-        if (Ops<T>::pack(d_q, nq, dim_eff, q_cols ? q_cols : 1, Qp, nq_pad, ix->ld, s) != hipSuccess) {
+        T *Qp = (T *)ws.w_q.p;
+        if (Ops<T>::pack((const T *)ws.w_hq.p, nq, dim_eff, q_cols ? q_cols : 1, Qp, nq_pad, ix->ld, s) != hipSuccess) {
             rc = fail(PN_ERR_DEVICE, "pack failed");
             break;
         }
         if constexpr (sizeof(T) == 4) {
             const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && ix->bf16_level < 2 &&
+            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
                 (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;
-                rc = radius_bf16(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
+                rc = radius_bf16(ix, ws, level, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
                 if (rc != PN_OK || done) break;
             }
             if (ix->mfma_ok && ix->ld <= 128 && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && finite_pos &&
                 (ix->engine == PN_ENGINE_MFMA || (ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;
-                rc = radius_mfma(ix, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
+                rc = radius_mfma(ix, ws, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
                 if (rc != PN_OK || done) break;
-                ix->stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
+                std::lock_guard<std::mutex> lk(ix->sh.mu);
+                ix->sh.stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
             }
         }
         std::vector<uint64_t> offs;
-        rc = radius_exact<T>(ix, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s);
+        rc = radius_exact<T>(ix, ws, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s);
         if (rc != PN_OK) break;
         memcpy(offsets, offs.data(), (nq + 1) * sizeof(uint64_t));
     } while (0);
     if (rc != PN_OK && *idx_out) { free(*idx_out); *idx_out = nullptr; }
-    if (d_q) (void)hipFree(d_q);
     return rc;
 }
 

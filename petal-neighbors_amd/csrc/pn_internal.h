@@ -66,12 +66,14 @@ inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // ---- exact_scan.hip
 // lo_key/lo_idx (nullable, [nq_pad]): only entries strictly after (lo_key[q], lo_idx[q]) take part
+// nq_dev (nullable) / nq_off: device-driven query count -- only the first min(nq, max(*nq_dev - nq_off, 0)) queries
+// exist; the grid is sized for nq and the surplus query tiles exit at once (second tier behind a filter)
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, hipStream_t s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, hipStream_t s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
 // radius: count pass (fill == nullptr) then fill pass.  counts/offsets are [query][seg].
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
@@ -95,28 +97,33 @@ hipError_t launch_cosine_pairwise_f64(const double *X, size_t n, int dim, size_t
 // records the last (key, row) written per query as the next round's lower bound
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, hipStream_t s);
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, hipStream_t s);
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).
 // qn / qbad (nullable, [nq]): the thresholds bound |q-p|^2 - |q|^2 (bf16 filter), qn[q] <= |q|^2 is added back;
 // qbad[q] != 0 flags the query outright
+// results of query q go to idx_out/dist_out[q * out_stride + r]; n_flagged: per-call count of flagged queries (device,
+// zeroed by the caller); stats (nullable): the index's running device counters {fallback queries, candidates, exact
+// evaluations}, added to from qstat (scratch [2 * nq]) and n_flagged by a one-block kernel behind the re-rank
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
-                                    uint64_t *idx_out, float *dist_out, uint32_t *flags,
-                                    uint32_t *n_flagged, uint64_t *n_cand, const double *qn, const uint32_t *qbad,
-                                    uint32_t *qstat /* scratch [2 * nq] for the statistics, nullable */, hipStream_t s);
+                                    uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *qstat,
+                                    unsigned long long *stats, hipStream_t s);
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s);
-// gather rows `sel[i]` of src into dst (row-padded), scatter results back
-hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, int nsel, float *dst,
-                                  hipStream_t s);
+// gather rows sel[off + i] of src into dst row i / scatter result rows i back to query sel[off + i], for
+// i < min(max_rows, *nsel - off): the count stays on the device
+hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
+                                  uint32_t max_rows, float *dst, hipStream_t s);
 hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel,
-                                      int nsel, int kout, uint64_t *idx_out, float *dist_out, hipStream_t s);
+                                      const uint32_t *nsel, uint32_t off, uint32_t max_rows, int kout, uint64_t *idx_out,
+                                      float *dist_out, size_t out_stride, hipStream_t s);
 hipError_t launch_compact_flags(const uint32_t *flags, int nq, uint32_t *sel, uint32_t *nsel, hipStream_t s);
 
 // ---- pack.hip
@@ -207,4 +214,12 @@ hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r,
 hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
                              hipStream_t s);
 
+}  // namespace pn
+
+// ---- index.hip, for the other translation units
+struct pn_index;
+namespace pn {
+int set_error(int code, const char *fmt, ...);
+int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s);
 }  // namespace pn

@@ -102,11 +102,16 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
                                                           uint64_t *__restrict__ idx_out, T *__restrict__ dist_out,
                                                           size_t out_stride, size_t out_off,
                                                           typename KeyOf<T>::type *__restrict__ lo_key,
-                                                          uint32_t *__restrict__ lo_idx) {
+                                                          uint32_t *__restrict__ lo_idx,
+                                                          const uint32_t *__restrict__ nq_dev, uint32_t nq_off) {
     using KeyT = typename KeyOf<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+    if (nq_dev) {  // device-driven query count (see launch_exact_knn_*)
+        const uint32_t tot = *nq_dev;
+        if (q >= (size_t)(tot > nq_off ? tot - nq_off : 0u)) return;
+    }
     int total_cap = 0;
     for (int s = 0; s < nseg; ++s) total_cap += (int)ccnt[(size_t)s * nq_pad + q];
     KeyT *skey = reinterpret_cast<KeyT *>(smem);
@@ -147,26 +152,27 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
 template <typename T>
 static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                       T *dist_out, int kp_bound, size_t out_stride, size_t out_off, void *lo_key,
-                                      uint32_t *lo_idx, hipStream_t s) {
+                                      uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
-                       index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx);
+                       index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx, nq_dev,
+                       nq_off);
     return hipGetLastError();
 }
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, hipStream_t s) {
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
     return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                      lo_key, lo_idx, s);
+                                      lo_key, lo_idx, nq_dev, nq_off, s);
 }
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, hipStream_t s) {
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
     return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                       lo_key, lo_idx, s);
+                                       lo_key, lo_idx, nq_dev, nq_off, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
     size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
-    float *__restrict__ dist_out, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
+    float *__restrict__ dist_out, size_t out_stride, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
     const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
     int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ qstat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -386,8 +392,8 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         const uint32_t ix = sidx[e];
         const uint32_t r = rank_of<uint32_t, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
-            idx_out[q * kout + r] = index_base + ix;
-            dist_out[q * kout + r] = key_to_dist(k);
+            idx_out[q * out_stride + r] = index_base + ix;
+            dist_out[q * out_stride + r] = key_to_dist(k);
             if (r == (uint32_t)kout - 1) kth_key = k;
         }
     }
@@ -420,8 +426,10 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     }
 }
 
-__global__ void stat_reduce_kernel(const uint32_t *__restrict__ qstat, int nq, unsigned long long *__restrict__ n_cand,
-                                   unsigned long long *__restrict__ n_eval) {
+// stats[0] += flagged queries of this call, stats[1] += candidates, stats[2] += exact evaluations (the index's
+// running device counters: the host reads them only when statistics are asked for)
+__global__ void stat_reduce_kernel(const uint32_t *__restrict__ qstat, int nq, const uint32_t *__restrict__ n_flagged,
+                                   unsigned long long *__restrict__ stats) {
     unsigned long long a = 0, b = 0;
     for (int i = threadIdx.x; i < nq; i += blockDim.x) {
         a += qstat[2 * i];
@@ -432,28 +440,27 @@ __global__ void stat_reduce_kernel(const uint32_t *__restrict__ qstat, int nq, u
         b += __shfl_xor(b, d);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(n_cand, a);
-        atomicAdd(n_eval, b);
+        atomicAdd(stats + 1, a);
+        atomicAdd(stats + 2, b);
     }
+    if (threadIdx.x == 0 && n_flagged) atomicAdd(stats, (unsigned long long)*n_flagged);
 }
 
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
-                                    uint64_t *idx_out, float *dist_out, uint32_t *flags, uint32_t *n_flagged,
-                                    uint64_t *n_cand, const double *qn, const uint32_t *qbad, uint32_t *qstat,
-                                    hipStream_t s) {
+                                    uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *qstat,
+                                    unsigned long long *stats, hipStream_t s) {
     // with filter keys in the buffers (both MFMA tiers) candidates are evaluated lazily
     const uint32_t *ckey = static_cast<const uint32_t *>(cb.keys);
     const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 12 + ((size_t)dim + 8) * sizeof(float);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
-                       ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, flags, n_flagged, qn, qbad,
-                       cb.idx_stride, ckey, qstat);
-    if (qstat && n_cand)  // n_cand[0] += candidates, n_cand[3] += exact evaluations
-        hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(1024), 0, s, qstat, nq,
-                           reinterpret_cast<unsigned long long *>(n_cand),
-                           reinterpret_cast<unsigned long long *>(n_cand) + 3);
+                       ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, out_stride, flags, n_flagged, qn,
+                       qbad, cb.idx_stride, ckey, qstat);
+    if (qstat && stats)
+        hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(1024), 0, s, qstat, nq, n_flagged, stats);
     return hipGetLastError();
 }
 
@@ -598,36 +605,47 @@ hipError_t launch_compact_flags(const uint32_t *flags, int nq, uint32_t *sel, ui
 }
 
 __global__ void gather_rows_kernel(const float *__restrict__ src, size_t ld, const uint32_t *__restrict__ sel,
-                                   int nsel, float *__restrict__ dst) {
-    const size_t i = blockIdx.x;
-    if (i >= (size_t)nsel) return;
-    const float *s = src + (size_t)sel[i] * ld;
-    float *d = dst + i * ld;
-    for (size_t c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
+                                   const uint32_t *__restrict__ nsel, uint32_t off, uint32_t max_rows,
+                                   float *__restrict__ dst) {
+    const uint32_t tot = *nsel;
+    uint32_t cnt = tot > off ? tot - off : 0u;
+    if (cnt > max_rows) cnt = max_rows;
+    for (size_t i = blockIdx.x; i < (size_t)cnt; i += gridDim.x) {
+        const float *s = src + (size_t)sel[off + i] * ld;
+        float *d = dst + i * ld;
+        for (size_t c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
+    }
 }
-hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, int nsel, float *dst,
-                                  hipStream_t s) {
-    if (nsel == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nsel), dim3(64), 0, s, src, ld, sel, nsel, dst);
+hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
+                                  uint32_t max_rows, float *dst, hipStream_t s) {
+    if (max_rows == 0) return hipSuccess;
+    const unsigned grid = max_rows < 1024u ? max_rows : 1024u;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(64), 0, s, src, ld, sel, nsel, off, max_rows, dst);
     return hipGetLastError();
 }
 
 __global__ void scatter_results_kernel(const uint64_t *__restrict__ idx_in, const float *__restrict__ dist_in,
-                                       const uint32_t *__restrict__ sel, int nsel, int kout,
-                                       uint64_t *__restrict__ idx_out, float *__restrict__ dist_out) {
-    const size_t i = blockIdx.x;
-    if (i >= (size_t)nsel) return;
-    const size_t q = sel[i];
-    for (int j = threadIdx.x; j < kout; j += blockDim.x) {
-        idx_out[q * kout + j] = idx_in[i * kout + j];
-        dist_out[q * kout + j] = dist_in[i * kout + j];
+                                       const uint32_t *__restrict__ sel, const uint32_t *__restrict__ nsel,
+                                       uint32_t off, uint32_t max_rows, int kout, uint64_t *__restrict__ idx_out,
+                                       float *__restrict__ dist_out, size_t out_stride) {
+    const uint32_t tot = *nsel;
+    uint32_t cnt = tot > off ? tot - off : 0u;
+    if (cnt > max_rows) cnt = max_rows;
+    for (size_t i = blockIdx.x; i < (size_t)cnt; i += gridDim.x) {
+        const size_t q = sel[off + i];
+        for (int j = threadIdx.x; j < kout; j += blockDim.x) {
+            idx_out[q * out_stride + j] = idx_in[i * kout + j];
+            dist_out[q * out_stride + j] = dist_in[i * kout + j];
+        }
     }
 }
-hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel, int nsel,
-                                      int kout, uint64_t *idx_out, float *dist_out, hipStream_t s) {
-    if (nsel == 0) return hipSuccess;
-    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)nsel), dim3(64), 0, s, idx_in, dist_in, sel, nsel,
-                       kout, idx_out, dist_out);
+hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel,
+                                      const uint32_t *nsel, uint32_t off, uint32_t max_rows, int kout, uint64_t *idx_out,
+                                      float *dist_out, size_t out_stride, hipStream_t s) {
+    if (max_rows == 0) return hipSuccess;
+    const unsigned grid = max_rows < 1024u ? max_rows : 1024u;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(grid), dim3(64), 0, s, idx_in, dist_in, sel, nsel, off, max_rows,
+                       kout, idx_out, dist_out, out_stride);
     return hipGetLastError();
 }
 

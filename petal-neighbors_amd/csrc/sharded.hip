@@ -1,0 +1,667 @@
+// sharded.hip -- row-sharded corpora behind the C ABI (include/petal_mi355x.h, pn_sharded_*): SURVEY.md 8(e).
+//
+// The corpus is split into contiguous row ranges (shard g = rows [g ceil(N/G), ...)), every shard is an ordinary
+// pn_index with PN_OPT_INDEX_BASE = its first row, queries are replicated, and the per-shard exact top-k -- written
+// straight into ONE packed buffer {idx[nq][k'] | dist[nq][k']} per GPU -- are exchanged by ONE RCCL all-gather per
+// query batch and merged by merge_topk_kernel under the (distance, index) order.  Exact top-k is decomposable and the
+// order is total, so the answer does not depend on the number of shards.
+//
+// Two ways to hold the shards:
+//   * pn_sharded_create_f32: ONE process drives n_devices GPUs (ncclCommInitAll over the distinct devices; a device
+//     named several times holds several shards, merged locally before the exchange -- this is also how the path is
+//     exercised on a single GPU);
+//   * pn_sharded_create_rank_device_f32: ONE process per GPU (the launch model of bench.py / torch.distributed.run);
+//     rank 0 obtains a communicator id from pn_comm_unique_id, the host program carries it to the other ranks by
+//     whatever means it has, every rank hands it in (ncclCommInitRank).
+// RCCL is loaded at run time (dlopen: the copy already in the process if there is one, e.g. PyTorch's), so the
+// library itself has no link-time dependency on it and CPU-only hosts can still load the ABI.
+//
+// Query batches above kShardChunk queries are cut into chunks whose exchange + merge run on a second stream while
+// the next chunk's filter runs on the caller's (two packed-buffer sets, events in both directions).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "../../include/petal_mi355x.h"
+#include "pn_internal.h"
+
+using namespace pn;
+
+#define SHIP(expr)                                                                                          \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return set_error(e_ == hipErrorOutOfMemory ? PN_ERR_NOMEM : PN_ERR_DEVICE, "%s: %s", #expr,     \
+                             hipGetErrorString(e_));                                                        \
+    } while (0)
+#define SPN(expr)                     \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != PN_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// RCCL, resolved at run time
+// ---------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    std::string err;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return handle != nullptr && err.empty(); }
+};
+
+Rccl load_rccl() {
+    Rccl r;
+    // the copy already mapped into the process first (PyTorch-ROCm ships its own): two RCCLs in one process would
+    // each keep their own view of the devices
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)
+        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *n : paths)
+        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) {
+        const char *e = dlerror();
+        r.err = std::string("RCCL is not loadable: ") + (e ? e : "unknown dlopen failure");
+        return r;
+    }
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(r.handle, name);
+        if (!p && r.err.empty()) r.err = std::string("RCCL does not export ") + name;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+}
+Rccl &rccl() {
+    static Rccl r = load_rccl();
+    return r;
+}
+int need_rccl() {
+    Rccl &r = rccl();
+    if (!r.ok()) return set_error(PN_ERR_COMM, "%s", r.err.c_str());
+    return PN_OK;
+}
+}  // namespace
+
+#define SNCCL(expr)                                                                                   \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess) return set_error(PN_ERR_COMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == PN_COMM_ID_BYTES, "PN_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+// ---------------------------------------------------------------------------
+// the sharded handle
+// ---------------------------------------------------------------------------
+namespace {
+constexpr size_t kShardChunk = 131072;  // queries per exchange when a batch is cut (two chunks in flight)
+
+struct Buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes && p) return PN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return set_error(PN_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        bytes = want;
+        return PN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Part {  // one row shard held by this process
+    pn_index *ix = nullptr;  // nullptr: the shard has no rows (N < number of shards)
+    uint64_t lo = 0, hi = 0;
+    int dev_slot = 0;
+};
+struct Dev {  // one GPU this process drives = one rank of the communicator
+    int device = 0;
+    int comm_rank = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;     // host entry points
+    hipStream_t comm_stream = nullptr;  // exchange + merge of a chunk while the next chunk is filtered
+    hipEvent_t ev_local[2] = {nullptr, nullptr}, ev_merged[2] = {nullptr, nullptr}, ev_done = nullptr;
+    std::vector<int> parts;
+    Buf q, out_idx, out_dist, lparts, pack[2], gathered[2], rad_a, rad_b;
+};
+struct SetGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit SetGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~SetGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+struct pn_sharded {
+    uint64_t n_total = 0;
+    size_t dim = 0;
+    uint64_t per = 0;  // rows per shard = ceil(n_total / n_shards)
+    int n_shards = 0;  // over all processes
+    int world = 1;     // ranks of the communicator (GPUs)
+    bool rank_mode = false;
+    std::vector<Part> parts;  // local ones
+    // queries take a `const pn_sharded *` (BallTree queries take &self); what they touch below -- streams, exchange
+    // buffers, the communicator -- is shared per-handle state, internally serialised by `mu`: one query at a time
+    mutable std::vector<Dev> devs;  // local ones
+    mutable std::mutex mu;
+};
+
+static size_t packed_words(size_t nq, size_t kp) { return nq * kp + (nq * kp + 1) / 2; }
+
+extern "C" int pn_comm_unique_id(void *id_out) {
+    if (!id_out) return set_error(PN_ERR_INVALID, "id_out is NULL");
+    SPN(need_rccl());
+    ncclUniqueId id;
+    SNCCL(rccl().GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return PN_OK;
+}
+
+static void destroy_dev(Dev &d) {
+    SetGuard g(d.device);
+    (void)hipDeviceSynchronize();
+    if (d.comm && rccl().ok()) (void)rccl().CommDestroy(d.comm);
+    Buf *bufs[] = {&d.q, &d.out_idx, &d.out_dist, &d.lparts, &d.pack[0], &d.pack[1], &d.gathered[0], &d.gathered[1],
+                   &d.rad_a, &d.rad_b};
+    for (Buf *b : bufs) b->release();
+    hipEvent_t evs[] = {d.ev_local[0], d.ev_local[1], d.ev_merged[0], d.ev_merged[1], d.ev_done};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.comm_stream) (void)hipStreamDestroy(d.comm_stream);
+}
+
+extern "C" void pn_sharded_destroy(pn_sharded *sh) {
+    if (!sh) return;
+    for (Part &p : sh->parts)
+        if (p.ix) pn_index_destroy(p.ix);
+    for (Dev &d : sh->devs) destroy_dev(d);
+    delete sh;
+}
+
+static int init_dev_resources(Dev &d) {
+    SetGuard g(d.device);
+    if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+    SHIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    SHIP(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        SHIP(hipEventCreateWithFlags(&d.ev_local[i], hipEventDisableTiming));
+        SHIP(hipEventCreateWithFlags(&d.ev_merged[i], hipEventDisableTiming));
+    }
+    SHIP(hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
+    return PN_OK;
+}
+
+// BallTree::new over n_devices row shards, one process.  Validation is the reference's
+// (src/ball_tree.rs:44-49), done on the whole array before anything is split.
+extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                     ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+    if (!out) return set_error(PN_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_rows == 0) return set_error(PN_ERR_EMPTY, "array is empty");
+    if (n_cols > 1 && col_stride != 1) return set_error(PN_ERR_NOT_CONTIGUOUS, "array is not contiguous in memory");
+    if (n_cols == 0 && n_rows >= 2) return set_error(PN_ERR_EMPTY_MATRIX, "empty matrix");
+    if (!devices || n_devices < 1 || n_devices > 64) return set_error(PN_ERR_INVALID, "devices: 1..64 entries");
+    if (!points && n_cols) return set_error(PN_ERR_INVALID, "points is NULL");
+    if (row_stride < 0) return set_error(PN_ERR_UNSUPPORTED, "negative row stride");
+    int n_gpu = 0;
+    SPN(pn_device_count(&n_gpu));
+    if (n_gpu <= 0) return set_error(PN_ERR_DEVICE, "no usable GPU; this library has no CPU path");
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= n_gpu)
+            return set_error(PN_ERR_INVALID, "device %d out of range [0,%d)", devices[i], n_gpu);
+    SPN(need_rccl());
+    pn_sharded *sh = new (std::nothrow) pn_sharded();
+    if (!sh) return set_error(PN_ERR_NOMEM, "host allocation failed");
+    sh->n_total = n_rows;
+    sh->dim = n_cols;
+    sh->n_shards = n_devices;
+    sh->per = (n_rows + (size_t)n_devices - 1) / (size_t)n_devices;
+    // distinct devices in order of first appearance = ranks of the communicator
+    std::vector<int> distinct;
+    for (int i = 0; i < n_devices; ++i)
+        if (std::find(distinct.begin(), distinct.end(), devices[i]) == distinct.end()) distinct.push_back(devices[i]);
+    sh->world = (int)distinct.size();
+    sh->devs.resize(distinct.size());
+    int rc = PN_OK;
+    for (size_t r = 0; r < distinct.size() && rc == PN_OK; ++r) {
+        sh->devs[r].device = distinct[r];
+        sh->devs[r].comm_rank = (int)r;
+        rc = init_dev_resources(sh->devs[r]);
+    }
+    for (int g = 0; g < n_devices && rc == PN_OK; ++g) {
+        Part p;
+        p.lo = std::min<uint64_t>(n_rows, (uint64_t)g * sh->per);
+        p.hi = std::min<uint64_t>(n_rows, p.lo + sh->per);
+        p.dev_slot = (int)(std::find(distinct.begin(), distinct.end(), devices[g]) - distinct.begin());
+        if (p.hi > p.lo) {
+            rc = pn_index_create_f32(points + (size_t)p.lo * (size_t)row_stride, (size_t)(p.hi - p.lo), n_cols, row_stride,
+                                     col_stride, devices[g], &p.ix);
+            if (rc == PN_OK) rc = pn_index_set_option(p.ix, PN_OPT_INDEX_BASE, (int64_t)p.lo);
+        }
+        sh->parts.push_back(p);
+        sh->devs[p.dev_slot].parts.push_back(g);
+    }
+    if (rc == PN_OK) {
+        std::vector<ncclComm_t> comms(distinct.size(), nullptr);
+        ncclResult_t r = rccl().CommInitAll(comms.data(), (int)distinct.size(), distinct.data());
+        if (r != ncclSuccess)
+            rc = set_error(PN_ERR_COMM, "ncclCommInitAll over %zu GPUs: %s", distinct.size(), rccl().GetErrorString(r));
+        for (size_t i = 0; i < distinct.size(); ++i) sh->devs[i].comm = comms[i];
+    }
+    if (rc != PN_OK) {
+        const std::string keep = pn_last_error();
+        pn_sharded_destroy(sh);
+        return set_error(rc, "%s", keep.c_str());
+    }
+    *out = sh;
+    return PN_OK;
+}
+
+// One process per GPU: this rank's rows (already on `device`) of an n_total-row corpus.  Shard bounds are the
+// library's: rank r holds rows [r ceil(N/W), min(N, (r+1) ceil(N/W))) -- n_local must be exactly that many (a rank
+// beyond the corpus passes n_local = 0 and still takes part in every exchange).
+extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
+                                                 uint64_t n_total, int rank, int world, const void *comm_id, int device,
+                                                 void *stream, pn_sharded **out) {
+    if (!out) return set_error(PN_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_total == 0) return set_error(PN_ERR_EMPTY, "array is empty");
+    if (world < 1 || rank < 0 || rank >= world) return set_error(PN_ERR_INVALID, "rank %d of %d", rank, world);
+    if (!comm_id) return set_error(PN_ERR_INVALID, "comm_id is NULL");
+    const uint64_t per = (n_total + (uint64_t)world - 1) / (uint64_t)world;
+    const uint64_t lo = std::min<uint64_t>(n_total, (uint64_t)rank * per), hi = std::min<uint64_t>(n_total, lo + per);
+    if ((uint64_t)n_local != hi - lo)
+        return set_error(PN_ERR_INVALID, "rank %d of %d holds rows [%llu, %llu) of %llu: n_local must be %llu, got %zu", rank,
+                         world, (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)n_total,
+                         (unsigned long long)(hi - lo), n_local);
+    int n_gpu = 0;
+    SPN(pn_device_count(&n_gpu));
+    if (device < 0 || device >= n_gpu) return set_error(PN_ERR_INVALID, "device %d out of range [0,%d)", device, n_gpu);
+    SPN(need_rccl());
+    pn_sharded *sh = new (std::nothrow) pn_sharded();
+    if (!sh) return set_error(PN_ERR_NOMEM, "host allocation failed");
+    sh->n_total = n_total;
+    sh->dim = n_cols;
+    sh->n_shards = world;
+    sh->world = world;
+    sh->per = per;
+    sh->rank_mode = true;
+    sh->devs.resize(1);
+    sh->devs[0].device = device;
+    sh->devs[0].comm_rank = rank;
+    int rc = init_dev_resources(sh->devs[0]);
+    Part p;
+    p.lo = lo;
+    p.hi = hi;
+    if (rc == PN_OK && hi > lo) {
+        rc = pn_index_create_device_f32(d_rows, n_local, n_cols, row_stride, device, stream, &p.ix);
+        if (rc == PN_OK) rc = pn_index_set_option(p.ix, PN_OPT_INDEX_BASE, (int64_t)lo);
+    }
+    sh->parts.push_back(p);
+    sh->devs[0].parts.push_back(0);
+    if (rc == PN_OK) {
+        SetGuard g(device);
+        ncclUniqueId id;
+        memcpy(&id, comm_id, sizeof id);
+        ncclResult_t r = rccl().CommInitRank(&sh->devs[0].comm, world, id, rank);
+        if (r != ncclSuccess)
+            rc = set_error(PN_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl().GetErrorString(r));
+    }
+    if (rc != PN_OK) {
+        const std::string keep = pn_last_error();
+        pn_sharded_destroy(sh);
+        return set_error(rc, "%s", keep.c_str());
+    }
+    *out = sh;
+    return PN_OK;
+}
+
+extern "C" int pn_sharded_info(const pn_sharded *sh, pn_sharded_info_t *out) {
+    if (!sh || !out) return set_error(PN_ERR_INVALID, "NULL argument");
+    out->n_points = sh->n_total;
+    out->dim = sh->dim;
+    out->n_shards = sh->n_shards;
+    out->world = sh->world;
+    out->local_shards = (int32_t)sh->parts.size();
+    out->rank = sh->rank_mode ? sh->devs[0].comm_rank : 0;
+    out->local_first_row = sh->parts.empty() ? 0 : sh->parts.front().lo;
+    out->local_rows = 0;
+    for (const Part &p : sh->parts) out->local_rows += p.hi - p.lo;
+    return PN_OK;
+}
+
+extern "C" int pn_sharded_set_option(pn_sharded *sh, int option, int64_t value) {
+    if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    if (option == PN_OPT_INDEX_BASE) return set_error(PN_ERR_INVALID, "the index base of a shard is its first row");
+    for (Part &p : sh->parts)
+        if (p.ix) SPN(pn_index_set_option(p.ix, option, value));
+    return PN_OK;
+}
+
+extern "C" int pn_sharded_get_stats(const pn_sharded *sh, pn_stats *out, int reset) {
+    if (!sh || !out) return set_error(PN_ERR_INVALID, "NULL argument");
+    pn_stats acc{};
+    for (const Part &p : sh->parts) {
+        if (!p.ix) continue;
+        pn_stats s{};
+        SPN(pn_index_get_stats(p.ix, &s, reset));
+        acc.queries += s.queries;
+        acc.fallback_queries += s.fallback_queries;
+        acc.candidates += s.candidates;
+        acc.hot_launches += s.hot_launches;
+        acc.hot_ms += s.hot_ms;
+        acc.last_call_ms += s.last_call_ms;
+        acc.radius_results += s.radius_results;
+        acc.evaluations += s.evaluations;
+    }
+    *out = acc;
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// k-NN
+// ---------------------------------------------------------------------------
+// The local half of one chunk on one GPU: every local shard's top-kp into the packed buffer `set` (several shards on
+// this GPU: merged to one packed buffer first).  Enqueued on `s`.
+static int enqueue_local(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                         size_t k, size_t kp, int set, hipStream_t s) {
+    const size_t words = packed_words(nq, kp);
+    SPN(d.pack[set].ensure(words * 8));
+    const size_t np = d.parts.size();
+    uint64_t *target = (uint64_t *)d.pack[set].p;
+    if (np > 1) {
+        SPN(d.lparts.ensure(np * words * 8));
+        target = (uint64_t *)d.lparts.p;
+    }
+    for (size_t i = 0; i < np; ++i) {
+        const Part &p = sh->parts[d.parts[i]];
+        uint64_t *pi = target + i * words;
+        float *pd = reinterpret_cast<float *>(pi + nq * kp);
+        const uint64_t rows = p.hi - p.lo;
+        if (rows < kp)  // absent slots: index ~0 (and a NaN distance) -- the merge kernel skips them
+            SHIP(hipMemsetAsync(pi, 0xFF, words * 8, s));
+        if (p.ix)
+            SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
+    }
+    if (np > 1) {
+        uint64_t *oi = (uint64_t *)d.pack[set].p;
+        float *od = reinterpret_cast<float *>(oi + nq * kp);
+        SPN(pn_merge_topk_device_f32((const uint64_t *)d.lparts.p, reinterpret_cast<const float *>((const uint64_t *)d.lparts.p + nq * kp),
+                                     np, words, 2 * words, nq, kp, kp, oi, od, d.device, s));
+    }
+    return PN_OK;
+}
+
+// exchange + final merge of one chunk on one GPU, enqueued on `s`: one all-gather of the packed buffer, then the
+// (distance, index) merge of the world's parts into d_idx/d_dist [nq][k_out]
+static int enqueue_merge(const pn_sharded *sh, Dev &d, size_t nq, size_t kp, size_t k_out, int set, uint64_t *d_idx,
+                         float *d_dist, hipStream_t s) {
+    const size_t words = packed_words(nq, kp);
+    const uint64_t *g = (const uint64_t *)d.gathered[set].p;
+    return pn_merge_topk_device_f32(g, reinterpret_cast<const float *>(g + nq * kp), (size_t)sh->world, words, 2 * words, nq,
+                                    kp, k_out, d_idx, d_dist, d.device, s);
+}
+
+static size_t k_part_of(const pn_sharded *sh, size_t k) {
+    const uint64_t largest = std::min<uint64_t>(sh->per, sh->n_total);  // shard 0 is never smaller than another
+    return (size_t)std::min<uint64_t>(k, largest ? largest : 1);
+}
+
+// rank mode (or one GPU): queries and results on this process's GPU, everything enqueued on `s`
+static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                            size_t k, uint64_t *d_idx, float *d_dist, hipStream_t s) {
+    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k);
+    SetGuard g(d.device);
+    if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+    const size_t chunk = nq > kShardChunk ? kShardChunk : nq;
+    const bool overlapped = nq > chunk;  // two chunks in flight: exchange + merge on the second stream
+    int set = 0;
+    size_t n_chunks = 0;
+    for (size_t q0 = 0; q0 < nq; q0 += chunk, set ^= 1, ++n_chunks) {
+        const size_t nqc = nq - q0 < chunk ? nq - q0 : chunk;
+        const size_t words = packed_words(nqc, kp);
+        SPN(d.gathered[set].ensure((size_t)sh->world * words * 8));
+        // the packed buffer of this set is free again once the exchange that read it (two chunks ago) has been merged
+        if (overlapped && n_chunks >= 2) SHIP(hipStreamWaitEvent(s, d.ev_merged[set], 0));
+        SPN(enqueue_local(sh, d, d_q + q0 * q_stride, nqc, q_cols, q_stride, k, kp, set, s));
+        hipStream_t xs = s;
+        if (overlapped) {
+            SHIP(hipEventRecord(d.ev_local[set], s));
+            SHIP(hipStreamWaitEvent(d.comm_stream, d.ev_local[set], 0));
+            xs = d.comm_stream;
+        }
+        SNCCL(rccl().AllGather(d.pack[set].p, d.gathered[set].p, words, ncclUint64, d.comm, xs));
+        SPN(enqueue_merge(sh, d, nqc, kp, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
+        if (overlapped) SHIP(hipEventRecord(d.ev_merged[set], xs));
+    }
+    if (overlapped) {  // results are ready in the order of the caller's stream
+        SHIP(hipEventRecord(d.ev_done, d.comm_stream));
+        SHIP(hipStreamWaitEvent(s, d.ev_done, 0));
+    }
+    return PN_OK;
+}
+
+extern "C" int pn_sharded_query_device_f32(const pn_sharded *sh, const float *d_queries, size_t nq, size_t q_cols,
+                                           size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out,
+                                           void *stream) {
+    if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total);
+    if (nq == 0 || k_out == 0) return PN_OK;  // k == 0 -> empty result (src/ball_tree.rs:106-108)
+    if (!d_queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
+    if (!d_idx_out || !d_dist_out) return set_error(PN_ERR_INVALID, "output buffer is NULL");
+    if (sh->devs.size() != 1)
+        return set_error(PN_ERR_UNSUPPORTED, "device-resident queries need a handle that drives ONE GPU (one process per "
+                                             "GPU, or all shards on one device); use pn_sharded_query_f32");
+    std::lock_guard<std::mutex> lk(sh->mu);
+    return query_device_one(sh, sh->devs[0], d_queries, nq, q_cols, q_row_stride, k, d_idx_out,
+                            d_dist_out, (hipStream_t)stream);
+}
+
+// Host entry point: BallTree::query over the sharded corpus for a batch of host queries.
+extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
+                                    ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out) {
+    if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k);
+    if (nq == 0 || k_out == 0) return PN_OK;
+    if (!queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
+    if (!idx_out || !dist_out) return set_error(PN_ERR_INVALID, "output buffer is NULL");
+    if (q_row_stride < 0) return set_error(PN_ERR_UNSUPPORTED, "negative row stride");
+    std::lock_guard<std::mutex> lk(sh->mu);
+    std::vector<Dev> &devs = sh->devs;
+    const size_t qc = q_cols ? q_cols : 1;
+    // queries to every GPU this process drives (replicated)
+    for (Dev &d : devs) {
+        SetGuard g(d.device);
+        if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+        SPN(d.q.ensure(nq * qc * sizeof(float)));
+        if (q_cols) {
+            if (nq == 1 || (size_t)q_row_stride == q_cols)
+                SHIP(hipMemcpyAsync(d.q.p, queries, nq * q_cols * sizeof(float), hipMemcpyHostToDevice, d.stream));
+            else
+                SHIP(hipMemcpy2DAsync(d.q.p, q_cols * sizeof(float), queries, (size_t)q_row_stride * sizeof(float),
+                                      q_cols * sizeof(float), nq, hipMemcpyHostToDevice, d.stream));
+        }
+    }
+    Dev &d0 = devs[0];
+    {
+        SetGuard g(d0.device);
+        SPN(d0.out_idx.ensure(nq * k_out * sizeof(uint64_t)));
+        SPN(d0.out_dist.ensure(nq * k_out * sizeof(float)));
+    }
+    if (devs.size() == 1) {
+        SPN(query_device_one(sh, d0, (const float *)d0.q.p, nq, q_cols, qc, k, (uint64_t *)d0.out_idx.p,
+                             (float *)d0.out_dist.p, d0.stream));
+    } else {
+        // one process, several GPUs: local work on every GPU, ONE grouped all-gather, merge on the first GPU
+        const size_t words = packed_words(nq, kp);
+        for (Dev &d : devs) {
+            SetGuard g(d.device);
+            SPN(d.gathered[0].ensure((size_t)sh->world * words * 8));
+            SPN(enqueue_local(sh, d, (const float *)d.q.p, nq, q_cols, qc, k, kp, 0, d.stream));
+        }
+        SNCCL(rccl().GroupStart());
+        for (Dev &d : devs) {
+            ncclResult_t r = rccl().AllGather(d.pack[0].p, d.gathered[0].p, words, ncclUint64, d.comm, d.stream);
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return set_error(PN_ERR_COMM, "ncclAllGather: %s", rccl().GetErrorString(r));
+            }
+        }
+        SNCCL(rccl().GroupEnd());
+        SetGuard g(d0.device);
+        SPN(enqueue_merge(sh, d0, nq, kp, k_out, 0, (uint64_t *)d0.out_idx.p, (float *)d0.out_dist.p, d0.stream));
+    }
+    {
+        SetGuard g(d0.device);
+        SHIP(hipMemcpyAsync(idx_out, d0.out_idx.p, nq * k_out * sizeof(uint64_t), hipMemcpyDeviceToHost, d0.stream));
+        SHIP(hipMemcpyAsync(dist_out, d0.out_dist.p, nq * k_out * sizeof(float), hipMemcpyDeviceToHost, d0.stream));
+    }
+    for (Dev &d : devs) {  // every GPU has left the collective before the call returns
+        SetGuard g(d.device);
+        SHIP(hipStreamSynchronize(d.stream));
+    }
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// radius
+// ---------------------------------------------------------------------------
+// BallTree::query_radius over the sharded corpus: per query the ascending global rows of every shard, shard after
+// shard -- shards are ascending row ranges, so the concatenation is ascending.  Local shards answer through
+// pn_query_radius_f32; with one process per GPU the variable-length lists travel by two all-gathers (counts, then the
+// lists padded to the longest) and are spliced on the host.
+extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
+                                           ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out) {
+    if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    if (!offsets || !idx_out) return set_error(PN_ERR_INVALID, "output pointer is NULL");
+    *idx_out = nullptr;
+    offsets[0] = 0;
+    if (nq == 0) return PN_OK;
+    if (!queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
+    std::lock_guard<std::mutex> lk(sh->mu);
+    const size_t np = sh->parts.size();
+    std::vector<std::vector<uint64_t>> offs(np, std::vector<uint64_t>(nq + 1, 0));
+    std::vector<uint64_t *> lists(np, nullptr);
+    struct Free {
+        std::vector<uint64_t *> &l;
+        ~Free() {
+            for (uint64_t *p : l) pn_free(p);
+        }
+    } free_lists{lists};
+    for (size_t i = 0; i < np; ++i)
+        if (sh->parts[i].ix)
+            SPN(pn_query_radius_f32(sh->parts[i].ix, queries, nq, q_cols, q_row_stride, radius, offs[i].data(), &lists[i]));
+    // local splice: per query, local shards in order
+    std::vector<uint64_t> l_cnt(nq, 0);
+    for (size_t i = 0; i < np; ++i)
+        for (size_t a = 0; a < nq; ++a) l_cnt[a] += offs[i][a + 1] - offs[i][a];
+    uint64_t l_total = 0;
+    for (size_t a = 0; a < nq; ++a) l_total += l_cnt[a];
+    std::vector<uint64_t> l_ids((size_t)l_total);
+    {
+        uint64_t w = 0;
+        for (size_t a = 0; a < nq; ++a)
+            for (size_t i = 0; i < np; ++i) {
+                const uint64_t c = offs[i][a + 1] - offs[i][a];
+                if (c) memcpy(l_ids.data() + w, lists[i] + offs[i][a], c * sizeof(uint64_t));
+                w += c;
+            }
+    }
+    if (!sh->rank_mode || sh->world == 1) {
+        uint64_t *res = (uint64_t *)malloc((l_total ? l_total : 1) * sizeof(uint64_t));
+        if (!res) return set_error(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)l_total);
+        if (l_total) memcpy(res, l_ids.data(), (size_t)l_total * sizeof(uint64_t));
+        uint64_t run = 0;
+        for (size_t a = 0; a < nq; ++a) {
+            offsets[a] = run;
+            run += l_cnt[a];
+        }
+        offsets[nq] = run;
+        *idx_out = res;
+        return PN_OK;
+    }
+    // one process per GPU: counts, then padded lists, by all-gather
+    Dev &d = sh->devs[0];
+    SetGuard g(d.device);
+    if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+    const size_t W = (size_t)sh->world;
+    SPN(d.rad_a.ensure((nq + W * nq) * 8));
+    uint64_t *d_cnt = (uint64_t *)d.rad_a.p, *d_all = d_cnt + nq;
+    SHIP(hipMemcpyAsync(d_cnt, l_cnt.data(), nq * 8, hipMemcpyHostToDevice, d.stream));
+    SNCCL(rccl().AllGather(d_cnt, d_all, nq, ncclUint64, d.comm, d.stream));
+    std::vector<uint64_t> all_cnt(W * nq);
+    SHIP(hipMemcpyAsync(all_cnt.data(), d_all, W * nq * 8, hipMemcpyDeviceToHost, d.stream));
+    SHIP(hipStreamSynchronize(d.stream));
+    std::vector<uint64_t> tot(W, 0);
+    uint64_t longest = 1;
+    for (size_t r = 0; r < W; ++r) {
+        for (size_t a = 0; a < nq; ++a) tot[r] += all_cnt[r * nq + a];
+        longest = std::max(longest, tot[r]);
+    }
+    SPN(d.rad_b.ensure((size_t)(longest + W * longest) * 8));
+    uint64_t *d_mine = (uint64_t *)d.rad_b.p, *d_lists = d_mine + longest;
+    if (l_total) SHIP(hipMemcpyAsync(d_mine, l_ids.data(), (size_t)l_total * 8, hipMemcpyHostToDevice, d.stream));
+    SNCCL(rccl().AllGather(d_mine, d_lists, (size_t)longest, ncclUint64, d.comm, d.stream));
+    std::vector<uint64_t> all_ids((size_t)(W * longest));
+    SHIP(hipMemcpyAsync(all_ids.data(), d_lists, (size_t)(W * longest) * 8, hipMemcpyDeviceToHost, d.stream));
+    SHIP(hipStreamSynchronize(d.stream));
+    uint64_t total = 0;
+    for (size_t r = 0; r < W; ++r) total += tot[r];
+    uint64_t *res = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+    if (!res) return set_error(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)total);
+    std::vector<uint64_t> pos(W, 0);
+    uint64_t w = 0;
+    for (size_t a = 0; a < nq; ++a) {
+        offsets[a] = w;
+        for (size_t r = 0; r < W; ++r) {
+            const uint64_t c = all_cnt[r * nq + a];
+            if (c) memcpy(res + w, all_ids.data() + r * longest + pos[r], (size_t)c * sizeof(uint64_t));
+            pos[r] += c;
+            w += c;
+        }
+    }
+    offsets[nq] = w;
+    *idx_out = res;
+    return PN_OK;
+}
