@@ -109,18 +109,142 @@ def cpu_baseline(n, dim, k, budget_queries=None):
     }
 
 
+def verify(out, queries, n, dim, nq, k, rank, world, index, gen):
+    """Parity leg, OUTSIDE the timed region, on the results of the last timed step (every rank holds the full answer):
+    properties on every query (ascending, in range, no duplicates); the returned distance re-derived by the scalar
+    metric for sampled (query, neighbour) pairs, rows regenerated from the counter hash; the CPU oracle's brute force
+    over a host-generated corpus on a sample of queries (corpora of at most 2M rows); at one GPU also bit-equality with
+    the exact engine on up to 2 048 queries."""
+    import threading
+    import oracle
+    import petal_neighbors_amd as pn
+    idx, dst = out
+    res = {"ok": True, "checks": []}
+
+    def chk(name, ok):
+        res["checks"].append(name if ok else name + ": FAILED")
+        res["ok"] = res["ok"] and bool(ok)
+
+    kk = idx.shape[1]
+    chk("ascending", bool((dst[:, 1:] >= dst[:, :-1]).all()) if kk > 1 else True)
+    chk("in range", bool(((idx >= 0) & (idx < n)).all()))
+    srt = torch.sort(idx, dim=1).values
+    chk("no duplicates", bool((srt[:, 1:] != srt[:, :-1]).all()) if kk > 1 else True)
+    # scalar metric on sampled pairs: rows come from the generator, not from any shard
+    m = pn.distance.Euclidean()
+    sel = np.linspace(0, nq - 1, 24).astype(np.int64)
+    qh, ih, dh = queries[sel].cpu().numpy(), idx[sel].cpu().numpy(), dst[sel].cpu().numpy()
+    ok = True
+    for a in range(len(sel)):
+        for j in (0, kk - 1):
+            row = oracle.fill_uniform(dim, SEED_P, int(ih[a, j]) * dim)
+            ok = ok and m.distance(qh[a], row).tobytes() == dh[a, j].tobytes()
+    chk("distance == Euclidean::distance(query, points[idx]) on 48 pairs", ok)
+    if n <= 2_000_000 and rank == 0:
+        pts = oracle.fill_uniform(n * dim, SEED_P).reshape(n, dim)
+        ns = 32
+        osel = np.linspace(0, nq - 1, ns).astype(np.int64)
+        oq = queries[osel].cpu().numpy()
+        want = [None] * ns
+        nth = min(usable_cores(), 16)
+
+        def work(t):
+            for a in range(t, ns, nth):
+                want[a] = oracle.brute_knn(pts, oq[a:a + 1], k)
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(nth)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        gi, gd = idx[osel].cpu().numpy().astype(np.uint64), dst[osel].cpu().numpy()
+        ok = all(np.array_equal(gi[a], want[a][0][0]) and gd[a].tobytes() == want[a][1][0].tobytes() for a in range(ns))
+        chk(f"oracle brute force on {ns} sampled queries", ok)
+    if world == 1 and index.engine.tree is not None:
+        tree = index.engine.tree
+        ne = min(nq, 2048)
+        esel = torch.linspace(0, nq - 1, ne, device=idx.device).long()
+        tree.set_engine("exact")
+        ei, ed = (tree.query_device(queries[esel].contiguous(), k))
+        torch.cuda.synchronize()
+        chk(f"exact engine on {ne} queries", torch.equal(ei, idx[esel]) and torch.equal(ed.view(torch.int32), dst[esel].view(torch.int32)))
+    return res
+
+
+def plumbing(args):
+    """--config c1: the reference's own harness shapes and call pattern (benches/ball_tree.rs:8-62) -- f64, one point
+    per call through the host API, queries = corpus rows -- plus BASELINE.json's configs[0] shape (1000 x 3, k = 2) and
+    the one-point-per-call latency at the headline shape.  GPU path and the CPU restatement side by side."""
+    import oracle
+    import petal_neighbors_amd as pn
+    oracle.build()
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(0xBA11)
+    res = {}
+
+    def timeit(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    # build: 128 x 10 f64, BallTree::euclidean(array) per iteration (benches/ball_tree.rs:8-20)
+    a = rng.random((128, 10))
+    res["build_128x10_f64"] = {"gpu_us": round(timeit(lambda: pn.BallTree.euclidean(a).close(), 20) * 1e6, 1),
+                               "cpu_port_us": round(timeit(lambda: oracle.Tree(a), 200) * 1e6, 1)}
+    # query: 64 x 10 f64, 64 calls per iteration, k = 5 (benches/ball_tree.rs:43-62)
+    a = rng.random((64, 10))
+    g, c = pn.BallTree.euclidean(a), oracle.Tree(a)
+    res["query_64x10_f64_k5"] = {"gpu_us_per_call": round(timeit(lambda: [g.query(a[i], 5) for i in range(64)], 20) / 64 * 1e6, 1),
+                                 "cpu_port_us_per_call": round(timeit(lambda: [c.query(a[i], 5) for i in range(64)], 50) / 64 * 1e6, 2)}
+    for i in range(64):  # parity on the way
+        gi, gd = g.query(a[i], 5)
+        ci, cd = c.query(a[i], 5)
+        assert gd.tobytes() == cd.tobytes() and list(gi) == list(ci)
+    # query_radius: 64 x 10 f64, 64 calls per iteration, r = 0.2 (benches/ball_tree.rs:22-41)
+    res["radius_64x10_f64_r0.2"] = {"gpu_us_per_call": round(timeit(lambda: [g.query_radius(a[i], 0.2) for i in range(64)], 20) / 64 * 1e6, 1),
+                                    "cpu_port_us_per_call": round(timeit(lambda: [c.query_radius(a[i], 0.2) for i in range(64)], 50) / 64 * 1e6, 2)}
+    for i in range(64):
+        assert sorted(int(x) for x in g.query_radius(a[i], 0.2)) == sorted(int(x) for x in c.query_radius(a[i], 0.2))
+    # BASELINE.json configs[0] as written: 1000 x 3 f64, k = 2
+    a = rng.random((1000, 3))
+    g, c = pn.BallTree.euclidean(a), oracle.Tree(a)
+    res["query_1000x3_f64_k2"] = {"gpu_us_per_call": round(timeit(lambda: [g.query(a[i], 2) for i in range(100)], 10) / 100 * 1e6, 1),
+                                  "cpu_port_us_per_call": round(timeit(lambda: [c.query(a[i], 2) for i in range(100)], 20) / 100 * 1e6, 2),
+                                  "gpu_us_per_query_batched": round(timeit(lambda: g.query_batch(a, 2), 20) / 1000 * 1e6, 3)}
+    # one point per call at the headline shape: 1M x 128 f32, k = 10
+    L = pn._lib.lib()
+    pts = torch.empty((1_000_000, 128), dtype=torch.float32, device="cuda:0")
+    assert L.pn_fill_uniform_device_f32(pts.data_ptr(), pts.numel(), SEED_P, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    big = pn.BallTree.from_device(pts)
+    q = oracle.fill_uniform(64 * 128, SEED_Q).reshape(64, 128)
+    res["query_1Mx128_f32_k10_one_point_per_call"] = {
+        "gpu_us_per_call": round(timeit(lambda: [big.query(q[i], 10) for i in range(64)], 5) / 64 * 1e6, 1),
+        "cpu_port_single_thread_qps_see_default_config": None}
+    line = {"metric": "one point per call, host API (benches/ball_tree.rs shapes; microseconds per call)",
+            "value": round(1e6 / res["query_64x10_f64_k5"]["gpu_us_per_call"], 1), "unit": "calls/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "n/a", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "c1: plumbing shapes of benches/ball_tree.rs (build 128x10, query 64x10 k=5, "
+                                   "radius 64x10 r=0.2) + BASELINE.json configs[0] (1000x3 k=2) + nq=1 at the headline shape"},
+            "results": res, "cpu_baseline": {"kind": "port", "cores": 1,
+                                             "sample": "C restatement of petal-neighbors' BallTree (oracle/), same arrays, one thread"}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c1"])
     ap.add_argument("--engine", default="auto", choices=["auto", "exact", "mfma", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
     ap.add_argument("--structure", type=int, default=0, help="PN_OPT_MFMA_STRUCTURE; 0 = auto")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity leg (outside the timed region)")
+    ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
+                    help="abi: the all-gather is RCCL behind the C ABI (pn_sharded_*); torch: torch.distributed")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -136,25 +260,32 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    if args.config == "c1":
+        return plumbing(args)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python bench.py --gpus N starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PN_BENCH_DIST") == "1"  # PN_BENCH_DIST=1: an nccl group even at world size 1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        rccl_world = dist.get_world_size()
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device(f"cuda:{local_rank if world > 1 else 0}")
+        rccl_world = 1
+    dev = torch.device(f"cuda:{local_rank if use_dist else 0}")
 
     import petal_neighbors_amd as pn
     from petal_neighbors_amd import _lib
-    from petal_neighbors_amd.sharded import ShardedBallTree, shard_bounds
+    from petal_neighbors_amd.sharded import AbiShardEngine, HipShardEngine, ShardedBallTree
     L = _lib.lib()
 
     n, dim, nq, k = CONFIGS[args.config]
@@ -167,26 +298,35 @@ def main():
 
     queries = gen(0, nq, SEED_Q)
     torch.cuda.synchronize()
-    index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P))
-    tree = index.engine.tree
-    tree.set_engine(args.engine)
-    if args.segments:
-        tree.set_option(_lib.PN_OPT_SEGMENTS, args.segments)
-    if args.slots:
-        tree.set_option(_lib.PN_OPT_FILTER_SLOTS, args.slots)
-    if args.structure:
-        tree.set_option(_lib.PN_OPT_MFMA_STRUCTURE, args.structure)
-    tree.set_option(_lib.PN_OPT_PROFILE, 1)
+    # "abi": the whole step (local shard, ONE ncclAllGather, merge) is one asynchronous call into the C ABI;
+    # "torch": the exchange is torch.distributed's all_gather_into_tensor (kept for comparison)
+    engine = AbiShardEngine(dev.index) if args.comm == "abi" else HipShardEngine(dev.index)
+    index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P), engine=engine)
+    tree = index.engine.tree  # None for a rank without rows on the torch path
+    if tree is not None:
+        tree.set_engine(args.engine)
+        if args.segments:
+            tree.set_option(_lib.PN_OPT_SEGMENTS, args.segments)
+        if args.slots:
+            tree.set_option(_lib.PN_OPT_FILTER_SLOTS, args.slots)
+        if args.structure:
+            tree.set_option(_lib.PN_OPT_MFMA_STRUCTURE, args.structure)
+        tree.set_option(_lib.PN_OPT_PROFILE, 1)
     n_local = index.n_local
+    out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device=dev)
+    out_dst = torch.empty((nq, min(k, n)), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step():
+        if args.comm == "abi":  # results land in preallocated buffers: nothing but the one C call per step
+            return index.engine.index.query_device(queries, k, out_idx, out_dst)
         return index.query_batch(queries, k)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    tree.stats(reset=True)
+    if tree is not None:
+        tree.stats(reset=True)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,7 +342,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = tree.stats()
+    st = tree.stats() if tree is not None else {"hot_launches": 0, "hot_ms": 0.0, "fallback_queries": 0, "candidates": 0,
+                                                 "queries": 0, "evaluations": 0}
+
+    verified = None
+    if not args.no_verify:
+        verified = verify(out, queries, n, dim, nq, k, rank, world, index, gen)
+        if dist:
+            v = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            verified["ok"] = bool(v.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -215,10 +364,10 @@ def main():
         # 2*N*D flop per query; a step of more than 262 144 queries is served in several launches
         flops_per_launch = 2.0 * n_local * dim * nq * args.steps / launches
         achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
-        if args.engine in ("auto", "bf16") and tree.bf16_eligible and n_local >= 4096 and dim >= 8:
+        if args.engine in ("auto", "bf16") and tree is not None and tree.bf16_eligible and n_local >= 4096 and dim >= 8:
             engine_used, peak = "bf16", PEAK_BF16_MFMA_TFLOPS
             kernel_name = "bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel"
-        elif args.engine != "exact" and tree.mfma_eligible:
+        elif args.engine != "exact" and tree is not None and tree.mfma_eligible:
             engine_used, peak = "mfma", PEAK_F32_MFMA_TFLOPS
             kernel_name = ("mfma_filter_wide_kernel" if dim > 128 else
                            "mfma_filter_v2_kernel" if (args.structure != 1 and k + 2 + k // 16 <= 224 and args.slots <= 224)
@@ -245,7 +394,11 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} points x {dim} dims f32, {nq} queries, k={k}, uniform[0,1)",
                        "n_points": n, "dim": dim, "n_queries": nq, "k": k, "engine": engine_used,
-                       "sharding": f"corpus rows / {world}" if world > 1 else "none"},
+                       "sharding": f"corpus rows / {world}" if world > 1 else "none",
+                       "exchange": ("none (one shard)" if world == 1 else
+                                    "one ncclAllGather per step behind the C ABI (pn_sharded_query_device_f32)"
+                                    if args.comm == "abi" else "torch.distributed.all_gather_into_tensor"),
+                       "rccl_world_size": rccl_world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
@@ -255,6 +408,8 @@ def main():
                          "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4),
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
                                                   / (peak * world), 4)},
+            "verified": bool(verified["ok"]) if verified else None,
+            "verify": verified,
             "fallback_queries": int(st["fallback_queries"]),
             "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
             "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),

@@ -83,8 +83,11 @@ enum {
     PN_OPT_INDEX_BASE = 3,  /* added to every returned index (row-sharded corpora) */
     PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream */
     PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
-    PN_OPT_MFMA_STRUCTURE = 6 /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
+    PN_OPT_MFMA_STRUCTURE = 6, /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
                                  buffers, 1 workgroup/CU; 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU */
+    PN_OPT_EXCHANGE_ALWAYS = 7 /* pn_sharded_set_option only.  A handle with ONE shard answers straight into the
+                                  caller's buffers (nothing to exchange); 1 sends it through the packed buffer, the
+                                  all-gather and the merge all the same (tests: RCCL at world size 1) */
 };
 
 typedef struct pn_index pn_index;
@@ -97,6 +100,9 @@ typedef struct pn_info {
     int32_t device;
     int32_t mfma_eligible; /* 1 when the f32 MFMA filter path can serve this index */
     int32_t bf16_eligible; /* 1 when the bf16 MFMA filter path can serve this index */
+    int32_t bf16_layout;   /* 0 none; 1 = five extra columns per row; 2 = row norm as the accumulator's initial value and
+                              a per-query error constant (rows of homogeneous norm, D mod 16 in {0, 12..15}) */
+    int32_t reserved;
 } pn_info;
 
 typedef struct pn_stats {
@@ -212,6 +218,29 @@ int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_pa
                              size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
                              size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device, void *stream);
 
+/* ---- tree introspection: BallTree::{num_nodes, children_of, points_of, radius_of, compare_nodes,
+ * node_distance_lower_bound} (src/ball_tree.rs:296-353), public in the reference for downstream dual-tree algorithms.
+ * Queries on this engine never use a tree; the first call of any function below builds -- once, on the host, from the
+ * index's own copy of the points -- the implicit complete binary ball tree exactly as the reference does
+ * (src/ball_tree.rs:38-63, 445-461, 504-613: node i has children 2i+1 / 2i+2, median split on the column of maximum
+ * spread, sequential-mean centroid, radius = largest distance to it), so every answer equals the reference's node for
+ * node.  O(n d log n) time and (nodes x d) extra host memory, paid only by callers of this API.
+ * A node number >= num_nodes is PN_ERR_INVALID (the reference panics).
+ *   children_of:   *is_some = 0 for a leaf (None), else 1 with (*left, *right) = (2n+1, 2n+2)
+ *   points_of:     *idx points INTO the tree's permutation (valid until pn_index_destroy), *count entries
+ *   compare_nodes: *ordering = -1 Less / 0 Equal / 1 Greater by radius, 2 = None (a NaN radius)
+ *   pn_tree_centroid_of: the node's centroid (n_cols elements of the index's type); private in the reference, exported
+ *                  for tests */
+int pn_tree_num_nodes(const pn_index *index, uint64_t *out);
+int pn_tree_children_of(const pn_index *index, uint64_t node, int *is_some, uint64_t *left, uint64_t *right);
+int pn_tree_points_of(const pn_index *index, uint64_t node, const uint64_t **idx, uint64_t *count);
+int pn_tree_radius_of_f32(const pn_index *index, uint64_t node, float *out);
+int pn_tree_radius_of_f64(const pn_index *index, uint64_t node, double *out);
+int pn_tree_compare_nodes(const pn_index *index, uint64_t x, uint64_t y, int *ordering);
+int pn_tree_node_distance_lower_bound_f32(const pn_index *index, uint64_t n1, uint64_t n2, float *out);
+int pn_tree_node_distance_lower_bound_f64(const pn_index *index, uint64_t n1, uint64_t n2, double *out);
+int pn_tree_centroid_of(const pn_index *index, uint64_t node, void *out_n_cols_elements);
+
 /* ---- row-sharded corpora with the exchange behind the ABI (north_star: "the corpus shards by row
  * across the 8 GPUs of one node, per-shard (idx, dist) top-k merged by one RCCL allgather over xGMI").  Shard g of G
  * holds rows [g ceil(N/G), min(N, (g+1) ceil(N/G))); queries are replicated; each shard answers on its rows with global
@@ -247,6 +276,8 @@ typedef struct pn_sharded_info_t {
     int32_t world;            /* ranks of the RCCL communicator = GPUs */
     int32_t local_shards;     /* shards held by this process */
     int32_t rank;             /* this process's rank (0 with one process) */
+    int32_t mfma_eligible;    /* every local shard can be served by the f32 MFMA filter / the bf16 filter (pn_info) */
+    int32_t bf16_eligible;
 } pn_sharded_info_t;
 int pn_comm_unique_id(void *id_out /* PN_COMM_ID_BYTES */);
 int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,

@@ -20,7 +20,7 @@ _lib.lib()  # fail loudly, at import, if the HIP library is missing
 from . import distance  # noqa: E402
 from .ball_tree import BallTree  # noqa: E402
 from .errors import ArrayError, PetalError  # noqa: E402
-from .sharded import ShardedBallTree  # noqa: E402
+from .sharded import ShardedBallTree, ShardedIndex  # noqa: E402
 from .vantage_point_tree import VantagePointTree  # noqa: E402
 
-__all__ = ["BallTree", "VantagePointTree", "ShardedBallTree", "ArrayError", "PetalError", "LibraryMissing", "distance"]
+__all__ = ["BallTree", "VantagePointTree", "ShardedBallTree", "ShardedIndex", "ArrayError", "PetalError", "LibraryMissing", "distance"]

@@ -9,19 +9,22 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpetal_mi355x.so")
+# PN_LIBRARY_PATH: a diagnostic build (build.py with PN_DIAG_FLAGS writes libpetal_mi355x_diag.so) for tools/ only
+LIB_PATH = os.environ.get("PN_LIBRARY_PATH") or os.path.join(_HERE, "libpetal_mi355x.so")
 
 PN_OK, PN_ERR_EMPTY, PN_ERR_NOT_CONTIGUOUS, PN_ERR_INVALID, PN_ERR_DEVICE, PN_ERR_NOMEM, \
-    PN_ERR_UNSUPPORTED, PN_ERR_EMPTY_MATRIX = range(8)
+    PN_ERR_UNSUPPORTED, PN_ERR_EMPTY_MATRIX, PN_ERR_COMM = range(9)
+PN_COMM_ID_BYTES = 128
 PN_ENGINE_AUTO, PN_ENGINE_EXACT, PN_ENGINE_MFMA, PN_ENGINE_BF16 = 0, 1, 2, 3
 PN_OPT_ENGINE, PN_OPT_SEGMENTS, PN_OPT_INDEX_BASE, PN_OPT_PROFILE, PN_OPT_FILTER_SLOTS = 1, 2, 3, 4, 5
 PN_OPT_MFMA_STRUCTURE = 6
+PN_OPT_EXCHANGE_ALWAYS = 7
 
 
 class PnInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("dim", C.c_uint64), ("row_stride_device", C.c_uint64),
                 ("elem_bytes", C.c_int32), ("device", C.c_int32), ("mfma_eligible", C.c_int32),
-                ("bf16_eligible", C.c_int32)]
+                ("bf16_eligible", C.c_int32), ("bf16_layout", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PnStats(C.Structure):
@@ -29,6 +32,13 @@ class PnStats(C.Structure):
                 ("hot_launches", C.c_uint64), ("hot_ms", C.c_double), ("last_call_ms", C.c_double),
                 ("radius_results", C.c_uint64), ("evaluations", C.c_uint64),
                 ("reserved", C.c_uint64 * 3)]
+
+
+class PnShardedInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("dim", C.c_uint64), ("local_first_row", C.c_uint64),
+                ("local_rows", C.c_uint64), ("n_shards", C.c_int32), ("world", C.c_int32),
+                ("local_shards", C.c_int32), ("rank", C.c_int32), ("mfma_eligible", C.c_int32),
+                ("bf16_eligible", C.c_int32)]
 
 
 _sz, _ssz, _i, _vp, _u64 = C.c_size_t, C.c_ssize_t, C.c_int, C.c_void_p, C.c_uint64
@@ -73,6 +83,25 @@ SIGNATURES = {
     "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
     "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp, _vp]),
+    "pn_tree_num_nodes": (_i, [_vp, _u64p]),
+    "pn_tree_children_of": (_i, [_vp, _u64, C.POINTER(_i), _u64p, _u64p]),
+    "pn_tree_points_of": (_i, [_vp, _u64, C.POINTER(_u64p), _u64p]),
+    "pn_tree_radius_of_f32": (_i, [_vp, _u64, _f32p]),
+    "pn_tree_radius_of_f64": (_i, [_vp, _u64, _f64p]),
+    "pn_tree_compare_nodes": (_i, [_vp, _u64, _u64, C.POINTER(_i)]),
+    "pn_tree_node_distance_lower_bound_f32": (_i, [_vp, _u64, _u64, _f32p]),
+    "pn_tree_node_distance_lower_bound_f64": (_i, [_vp, _u64, _u64, _f64p]),
+    "pn_tree_centroid_of": (_i, [_vp, _u64, _vp]),
+    "pn_comm_unique_id": (_i, [_vp]),
+    "pn_sharded_create_f32": (_i, [_vp, _sz, _sz, _ssz, _ssz, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "pn_sharded_create_rank_device_f32": (_i, [_vp, _sz, _sz, _sz, _u64, _i, _i, _vp, _i, _vp, C.POINTER(_vp)]),
+    "pn_sharded_destroy": (None, [_vp]),
+    "pn_sharded_info": (_i, [_vp, C.POINTER(PnShardedInfo)]),
+    "pn_sharded_set_option": (_i, [_vp, _i, C.c_int64]),
+    "pn_sharded_get_stats": (_i, [_vp, C.POINTER(PnStats), _i]),
+    "pn_sharded_query_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
+    "pn_sharded_query_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "pn_sharded_query_radius_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_float, _vp, C.POINTER(_vp)]),
 }
 
 _lib = None

@@ -46,6 +46,7 @@ class BallTree:
         self._n, self._dim = int(info.n_points), int(info.dim)
         self.mfma_eligible = bool(info.mfma_eligible)
         self.bf16_eligible = bool(info.bf16_eligible)
+        self.bf16_layout = int(info.bf16_layout)
 
     # ------------------------------------------------------------ construction
     @classmethod
@@ -134,6 +135,57 @@ class BallTree:
     @property
     def dim(self) -> int:
         return self._dim
+
+    # Tree introspection (src/ball_tree.rs:296-353).  No tree exists until one of these is called; the library then
+    # builds the reference's implicit ball tree once, on the host (csrc/tree.cpp) -- queries never use it.
+    def num_nodes(self) -> int:
+        """``BallTree::num_nodes`` (src/ball_tree.rs:345-348)."""
+        out = C.c_uint64(0)
+        check(_lib.lib().pn_tree_num_nodes(self._h, C.byref(out)))
+        return int(out.value)
+
+    def _node(self, n):
+        n = int(n)
+        if n < 0 or n >= self.num_nodes():
+            raise IndexError(f"node {n} out of range")  # the reference panics
+        return n
+
+    def children_of(self, n: int):
+        """``BallTree::children_of(n) -> Option<(usize, usize)>`` (src/ball_tree.rs:320-329): None for a leaf."""
+        some, left, right = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        check(_lib.lib().pn_tree_children_of(self._h, self._node(n), C.byref(some), C.byref(left), C.byref(right)))
+        return (int(left.value), int(right.value)) if some.value else None
+
+    def points_of(self, n: int):
+        """``BallTree::points_of(n) -> &[usize]`` (src/ball_tree.rs:331-334): the node's slice of ``idx``."""
+        ptr, cnt = C.POINTER(C.c_uint64)(), C.c_uint64(0)
+        check(_lib.lib().pn_tree_points_of(self._h, self._node(n), C.byref(ptr), C.byref(cnt)))
+        return np.ctypeslib.as_array(ptr, shape=(int(cnt.value),)).copy() if cnt.value else np.empty(0, dtype=np.uint64)
+
+    def radius_of(self, n: int):
+        """``BallTree::radius_of(n)`` (src/ball_tree.rs:336-339)."""
+        out = C.c_float(0) if self._sfx == "f32" else C.c_double(0)
+        check(getattr(_lib.lib(), f"pn_tree_radius_of_{self._sfx}")(self._h, self._node(n), C.byref(out)))
+        return self.dtype.type(out.value)
+
+    def compare_nodes(self, x: int, y: int):
+        """``BallTree::compare_nodes(x, y) -> Option<Ordering>`` by radius (src/ball_tree.rs:340-343):
+        -1 / 0 / 1 for Less / Equal / Greater, None when a radius is NaN."""
+        out = C.c_int(0)
+        check(_lib.lib().pn_tree_compare_nodes(self._h, self._node(x), self._node(y), C.byref(out)))
+        return None if out.value == 2 else int(out.value)
+
+    def node_distance_lower_bound(self, n1: int, n2: int):
+        """``BallTree::node_distance_lower_bound(n1, n2)`` = max(|c1 - c2| - R1 - R2, 0) (src/ball_tree.rs:303-318)."""
+        out = C.c_float(0) if self._sfx == "f32" else C.c_double(0)
+        check(getattr(_lib.lib(), f"pn_tree_node_distance_lower_bound_{self._sfx}")(self._h, self._node(n1), self._node(n2),
+                                                                                      C.byref(out)))
+        return self.dtype.type(out.value)
+
+    def _centroid_of(self, n: int):
+        c = np.empty(self._dim, dtype=self.dtype)
+        check(_lib.lib().pn_tree_centroid_of(self._h, self._node(n), c.ctypes.data))
+        return c
 
     # ------------------------------------------------------------------ queries
     def _queries(self, q, one: bool):

@@ -18,9 +18,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-BUILD = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libpetal_mi355x.so")
 ARCH = "gfx950"
+# diagnostic (timing-only / instrumented) builds: PN_DIAG_FLAGS="-DPN_DIAG_BF_COUNT" python build.py
+# They are a DIFFERENT library in a different object directory (libpetal_mi355x_diag.so, build_diag/): some of those
+# flags give wrong results by design, and nothing a diagnostic build does may touch the product library.  Load one with
+# PN_LIBRARY_PATH=<path> (petal-neighbors_amd/_lib.py).
+DIAG = os.environ.get("PN_DIAG_FLAGS", "").split()
+BUILD = os.path.join(HERE, "build_diag" if DIAG else "build")
+LIB = os.path.join(HERE, "libpetal_mi355x_diag.so" if DIAG else "libpetal_mi355x.so")
 
 # (source, extra flags)
 UNITS = [
@@ -33,11 +38,10 @@ UNITS = [
     ("bf16_filter.hip", []),
     ("sharded.hip", []),
     ("metric.cpp", ["-ffp-contract=off"]),
+    ("tree.cpp", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-# diagnostic (timing-only) builds: PN_DIAG_FLAGS="-DPN_DIAG_NO_SLOWPATH" python build.py --force
-DIAG = os.environ.get("PN_DIAG_FLAGS", "").split()
 HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(CSRC, "topk_buffer.h"),
            os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
 
@@ -59,6 +63,16 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) -> str:
     os.makedirs(BUILD, exist_ok=True)
     cc = hipcc()
+    # the flag set the objects were built with is part of their identity: a diagnostic (wrong-result) build must
+    # never survive into a later plain build() -- a changed flag set rebuilds everything
+    stamp = os.path.join(BUILD, ".flags")
+    flags_now = " ".join(COMMON + DIAG)
+    try:
+        flags_then = open(stamp).read()
+    except OSError:
+        flags_then = None
+    if flags_then != flags_now:
+        force = True
     objs = []
     me = os.path.abspath(__file__)
     for src, extra in UNITS:
@@ -80,7 +94,18 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return LIB
+
+
+def build_flags() -> str:
+    """Diagnostic flags of the library as built (empty for the product build)."""
+    try:
+        txt = open(os.path.join(BUILD, ".flags")).read()
+    except OSError:
+        return "?"
+    return " ".join(x for x in txt.split() if x.startswith("-DPN_DIAG"))
 
 
 if __name__ == "__main__":

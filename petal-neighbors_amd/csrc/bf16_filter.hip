@@ -42,8 +42,8 @@
 //    stores into the (segment, query) buffers the select kernel reads -- no LDS atomics, no fences on
 //    the fast path, no flush copy; the tile barrier waits for the LDS-DMA but not for those stores
 //    (bf_wait_dma);
-//  * the low four mantissa bits of a bound carry its accumulator register number, so the minimum of a
-//    lane's 16 bounds names its row (bf_chain<EMB>, bf_slow);
+//  * the fast path per 16 bounds is a v_min3 tree and one compare -- the loop is bound by vector-instruction issue,
+//    not by the matrix pipe; the row a surviving minimum belongs to is found in the rare path (bf_slow);
 //  * thresholds do not start at +inf: a scout pass over the run's first tiles seeds them -- within the
 //    launch from the run's own rows, or, with several segments per query, in a scout-only launch whose
 //    lists bf16_seed_kernel merges per query over all segments (host: bf16_plan in index.hip).
@@ -61,7 +61,20 @@ typedef const __attribute__((address_space(1))) void glb_void_b;
 
 #ifdef PN_DIAG_BF_COUNT  // diagnostic build only: event counters
 __device__ unsigned long long g_bfdbg[8];
-#define BF_COUNT(i, v) atomicAdd(&g_bfdbg[i], (unsigned long long)(v))
+// per-wave accumulators in registers (dbg_), flushed by one atomic per counter at the end of a run: an atomic per
+// event would itself be what the barrier waits for
+#define BF_COUNT(i, v) (dbg_[i] += (unsigned long long)(v))
+#define BF_DBG_DECL unsigned long long dbg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BF_DBG_ARG , unsigned long long (&dbg_)[8]
+#define BF_DBG_PASS , dbg_
+#define BF_DBG_FLUSH(lane)                                                        \
+    do {                                                                          \
+        if ((lane) == 0)                                                          \
+            for (int i_ = 0; i_ < 8; ++i_) {                                      \
+                atomicAdd(&g_bfdbg[i_], dbg_[i_]);                                \
+                dbg_[i_] = 0;                                                     \
+            }                                                                     \
+    } while (0)
 __device__ __forceinline__ unsigned long long bf_stamp() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -69,6 +82,10 @@ __device__ __forceinline__ unsigned long long bf_stamp() {
 }
 #else
 #define BF_COUNT(i, v) ((void)0)
+#define BF_DBG_DECL ((void)0)
+#define BF_DBG_ARG
+#define BF_DBG_PASS
+#define BF_DBG_FLUSH(lane) ((void)0)
 #endif
 
 constexpr int kBQ = 256;  // queries per workgroup (4 waves x 64)
@@ -82,6 +99,20 @@ __host__ __device__ inline int bf16_extra_col(int dim) {
     return room >= 5 && dim > 16 ? dim : (dim + 15) / 16 * 16;
 }
 __host__ __device__ inline int bf16_steps(int dim) { return (bf16_extra_col(dim) + 5 + 15) / 16; }
+// "Norm in the accumulator" layout (CI), for row lengths whose five extra columns would cost an MFMA step of their own
+// (D mod 16 in {0, 12..15}; D = 128: 8 steps instead of 9, D = 96: 6 instead of 7).  The extra columns disappear:
+//   * |p|^2 (1 - g), rounded down to f32, enters the chain as the accumulator's INITIAL value (the C operand of the
+//     first MFMA step) instead of as three bf16 pieces -- the row norms travel in the tile image's padding chunks;
+//   * the two error products Aq Bp + Cq Dp are replaced by the per-QUERY constant E(q) = Aq Bmax + Cq Dmax with the
+//     corpus-wide maxima of Bp, Dp.  A per-query constant shifts all of a query's bounds alike, so it never enters
+//     the kernel: comparisons, thresholds and keys are unchanged, and the proof adds |q|^2 - E(q) back where it used to
+//     add |q|^2 (pack_queries writes that difference, rounded down, into qn).
+// L'(q,p) - E(q) <= |q-p|^2 - |q|^2 holds exactly as in the header (Bmax >= Bp, Dmax >= Dp; the accumulation
+// allowance g (|C| + sum |products|) is paid by the (1 - g) on the norm and the 2g|p^| inside Bp as before).  The price
+// is slack where row norms differ a lot inside one corpus, so the index uses this layout only when
+// Bmax <= 1.3 mean(Bp) and Dmax <= 1.3 mean(Dp) (bf16_row_stats_kernel; uniform [0,1) 1M x 128: 1.16 / 1.18).
+__host__ __device__ inline bool bf16_ci_dim(int dim) { return dim >= 17 && dim <= 128 && bf16_steps(dim) > (dim + 15) / 16; }
+__host__ __device__ inline int bf16_steps_for(int dim, bool ci) { return ci ? (dim + 15) / 16 : bf16_steps(dim); }
 
 // ---------------------------------------------------------------------------
 // bf16 helpers on raw bits (host of the proofs above: every rounding direction is explicit)
@@ -148,20 +179,29 @@ __device__ __forceinline__ size_t bf_wide_at(size_t r, int k, int dim) {  // bf1
 // narrow (D <= 128): img = [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
 __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
                                         size_t ld, int KS, uint16_t *__restrict__ img, size_t n_rows_img,
-                                        uint32_t *__restrict__ bad, int wide) {
+                                        uint32_t *__restrict__ bad, int wide, int ci) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows_img) return;
     const int CP = 2 * KS + 1;
     const int E = bf16_extra_col(dim);
     auto at = [&](int k) -> uint16_t & { return wide ? img[bf_wide_at(r, k, dim)] : img[r * (size_t)CP * 8 + k]; };
+    // CI layout: the f32 norm of row rr of a tile lives in the padding chunk of the tile's row rr / 4, slot rr % 4
+    float *norm_slot = nullptr;
+    if (ci) {
+        const size_t t = r / kBP, rr = r % kBP;
+        norm_slot = reinterpret_cast<float *>(img + ((t * kBP + rr / 4) * (size_t)CP + (size_t)(CP - 1)) * 8) + (rr % 4);
+    }
     if (wide) {
         const int ncol = 64 * bf16_wide_nkc(dim) + (bf16_wide_has_x(dim) ? 16 : 0);
         for (int k = 0; k < ncol; ++k) at(k) = 0;
     } else {
-        for (int k = 0; k < CP * 8; ++k) at(k) = 0;
+        // CI: the padding chunks of a tile's first 16 rows are written by the rows whose norms they hold
+        const int nz = (ci && (r % kBP) < 16) ? (CP - 1) * 8 : CP * 8;
+        for (int k = 0; k < nz; ++k) at(k) = 0;
     }
     if (r >= n) {
-        at(E) = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+        // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+        if (ci) *norm_slot = 1.7e38f; else at(E) = 0x7F00u;
         return;
     }
     double pn = 0.0, en = 0.0, hn = 0.0;
@@ -182,7 +222,11 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     }
     if (!finite || !(pn < 1.2676506002282294e30)) {  // 2^100
         atomicOr(bad, 1u);
-        at(E) = 0x7F80u;
+        if (ci) *norm_slot = 1.7e38f; else at(E) = 0x7F80u;
+        return;
+    }
+    if (ci) {  // |p|^2 (1 - g), rounded down to f32: the chain's initial accumulator value
+        *norm_slot = f_down(pn * (1.0 - kG) / kUp);
         return;
     }
     // |p|^2 (1 - g), rounded down, in three truncated bf16 pieces
@@ -200,10 +244,54 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     at(E + 4) = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
 }
 
+// The per-row constants Bp, Dp of the bound over the whole corpus (f64, before their bf16 rounding): out[0] = max Bp,
+// out[1] = max Dp (bit patterns of non-negative doubles order like integers), out[2] = sum Bp, out[3] = sum Dp.
+// Decides whether the CI layout serves this corpus and provides the maxima E(q) is built from.
+__global__ void bf16_row_stats_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
+                                      size_t ld, double *__restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double bp = 0.0, dp = 0.0;
+    if (r < n) {
+        double pn = 0.0, en = 0.0, hn = 0.0;
+        bool finite = true;
+        const float *src = P + r * ld;
+        for (int k = 0; k < dim; ++k) {
+            const float x = src[k];
+            finite = finite && (fabsf(x) < 1.0e30f);
+            const double c = (double)x - (double)mu[k];
+            const float cf = (float)c;
+            const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
+            const double xh = (double)bf_f(hb);
+            pn += c * c;
+            en += (c - xh) * (c - xh);
+            hn += xh * xh;
+        }
+        if (finite && pn < 1.2676506002282294e30) {
+            bp = (2.0 * sqrt(en) * kUp + 2.0 * kG * sqrt(hn) * kUp) * (1.0 + 2.0 * kG) * kUp;
+            dp = 2.0 * sqrt(pn) * kUp * (1.0 + 2.0 * kG) * kUp;
+        }
+    }
+    double bm = bp, dm = dp, bs = bp, ds = dp;
+    for (int d = 32; d > 0; d >>= 1) {
+        bm = fmax(bm, __shfl_xor(bm, d));
+        dm = fmax(dm, __shfl_xor(dm, d));
+        bs += __shfl_xor(bs, d);
+        ds += __shfl_xor(ds, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(bm));
+        atomicMax(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)__double_as_longlong(dm));
+        atomicAdd(out + 2, bs);
+        atomicAdd(out + 3, ds);
+    }
+}
+
 // One thread per (padded) query: bf16 B row [K] (chunk c at 8c), |q|^2 rounded down (f64), flag.
+// ci: no extra columns; qn[q] = |q|^2 (down) - E(q) (up), E(q) = Aq bmax + Cq dmax (header of bf16_ci_dim)
 __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
                                          size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
-                                         double *__restrict__ qn, uint32_t *__restrict__ qbad, int wide) {
+                                         double *__restrict__ qn, uint32_t *__restrict__ qbad, int wide, int ci,
+                                         double bmax, double dmax) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
     const int K = 16 * KS, E = bf16_extra_col(dim);
@@ -233,6 +321,14 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
         }
     }
     const bool ok = finite && (s < 1.2676506002282294e30);
+    if (ci) {
+        if (!ok)
+            for (int k = 0; k < dim; ++k) at(k) = 0;
+        const double eq = (sqrt(hn) * kUp * bmax + sqrt(en) * kUp * dmax) * kUp;
+        qn[q] = ok ? s / kUp - eq : 0.0;
+        qbad[q] = ok ? 0u : 1u;
+        return;
+    }
     at(E + 0) = 0x3F80u;  // 1.0
     at(E + 1) = 0x3F80u;
     at(E + 2) = 0x3F80u;
@@ -311,16 +407,18 @@ __device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, i
 // KS-step chain of one 32-row block against the wave's two query blocks, while the VALU takes the
 // minimum of the OTHER block's bounds (r0, r1) in the matrix pipe's shadow.  The first kLA fragments
 // were read by the caller right behind the barrier; fragment ks + kLA is requested at step ks.
-// EMB: the register number i replaces the low four mantissa bits of bound i before the minimum is taken (one
-// v_and_or_b32 each), so the minimum itself says which register -- i.e. which row -- it came from, and the
-// rare path needs no search.  The filter then works on these tagged values throughout (comparison, stored key,
-// threshold); they differ from the bounds by less than 2^-19 relative, which the proof in select.hip subtracts.
+// The vector unit is the scarce resource of this loop, not the matrix pipe: an MFMA leaves room for ~6 vector
+// instructions per wave pair, so the fast path does nothing per bound but the v_min3 tree (8 instructions per 16
+// bounds); which row a surviving minimum belongs to is found in the rare path (bf_slow) by one compare per register.
+// (Round 1 tagged every bound with its register number first -- one v_and_or_b32 each, 2/3 of the fast path's vector
+// work -- so that the rare path needed no search; with seeded thresholds the rare path is rare enough to search.)
+// CI: the chain starts from c0 (the 16 row norms of this lane's rows) instead of zero.
 constexpr int kLA = 3;
 constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
-template <int KS, bool EMB>
+template <int KS, bool CI>
 __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
-                                         const bf16x8 (&b1)[KS], f32x16 &w0, f32x16 &w1, f32x16 &r0, f32x16 &r1,
-                                         float &m0, float &m1) {
+                                         const bf16x8 (&b1)[KS], const f32x16 &c0, f32x16 &w0, f32x16 &w1, f32x16 &r0,
+                                         f32x16 &r1, float &m0, float &m1) {
     bf16x8 f[KS];
 #pragma unroll
     for (int i = 0; i < kLA && i < KS; ++i) f[i] = pre[i];
@@ -330,9 +428,14 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + kLA < KS) f[ks + kLA] = *reinterpret_cast<const bf16x8 *>(arow + 32 * (ks + kLA));
-        w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : z, 0, 0, 0);
-        w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : z, 0, 0, 0);
-#ifdef PN_DIAG_BF_NOSCAN  // timing-only: no tag, no minimum
+        if (CI) {
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : c0, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : c0, 0, 0, 0);
+        } else {
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : z, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : z, 0, 0, 0);
+        }
+#ifdef PN_DIAG_BF_NOSCAN  // timing-only: no minimum
         if (ks == 0) {
             m0 = __uint_as_float(0x7F800000u);
             m1 = m0;
@@ -342,13 +445,6 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
 #else
         if (ks == 0) {
 #endif
-            if (EMB) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    r0[i] = __uint_as_float((__float_as_uint(r0[i]) & 0xFFFFFFF0u) | (uint32_t)i);
-                    r1[i] = __uint_as_float((__float_as_uint(r1[i]) & 0xFFFFFFF0u) | (uint32_t)i);
-                }
-            }
             float x = r0[0], y = r1[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
@@ -361,16 +457,37 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
     }
 }
 
+// CI layout: the norms of this lane's 16 rows of 32-row block `blk` (C/D map of the 32x32 MFMA: register r holds row
+// (r & 3) + 8 (r >> 2) + 4 h).  The norms of rows 4i .. 4i+3 of a tile sit in the padding chunk of its row i.
+template <int CP>
+__device__ __forceinline__ f32x16 bf_cinit(const char *tb, int blk, int h) {
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x16 c;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4_ v = *reinterpret_cast<const f32x4_ *>(tb + ((blk * 8 + 2 * g + h) * CP + (CP - 1)) * 16);
+        c[4 * g + 0] = v[0];
+        c[4 * g + 1] = v[1];
+        c[4 * g + 2] = v[2];
+        c[4 * g + 3] = v[3];
+    }
+    return c;
+}
+
 // append this lane's survivors of one (32-row block, query block) and compact the buffers that filled up.
 // cnt is the fill count of the lane's query (identical in lanes j and j+32, which hold different rows).
 // ns counts the vector-memory instructions this wave has issued since its last LDS-DMA (wave-uniform): the
 // wait in front of the tile barrier must cover the DMA but not these younger stores (see bf_wait_dma).
+// One compare per accumulator register, each answered for the whole wave as a scalar mask; a register without a
+// survivor in any lane costs that compare and a scalar branch, the (typically one) register with survivors a short
+// append block.  The threshold is laundered through an empty asm first: the compiler otherwise hoists these compares
+// into the hot loop, where they cost what the whole fast path costs.
 // RAD (radius queries): the threshold is the query's fixed radius bound and every row below it must be kept, so
 // a buffer that would need compacting is marked overflowed instead (count > capacity; the host re-runs the call
 // on the exact engine) and its threshold drops to -inf so that nothing more is stored.
 template <int M, bool RAD>
-__device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
-                                        int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk, uint32_t &ns) {
+__device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t &cnt, uint32_t row0, int h, int jq,
+                                        int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk, uint32_t &ns BF_DBG_ARG) {
 #ifdef PN_DIAG_BF_NOSLOW  // timing-only build: results are wrong
     asm volatile("" ::"v"(acc[0]), "v"(tau));
 #ifdef PN_DIAG_BF_FAKESLOW
@@ -379,57 +496,34 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
     return;
 #endif
     constexpr uint32_t CAP = 64u * M;
-    if (lane == 0) BF_COUNT(0, 1);
+    BF_COUNT(0, 1);
 #ifdef PN_DIAG_BF_COUNT
     const unsigned long long t0_ = bf_stamp();
+    unsigned long long tc_ = 0;
 #endif
+    float t = tau;
+    asm volatile("" : "+v"(t));  // opaque from here on: nothing below can be speculated above the caller's branch
     const uint32_t rowb = row0 + 4 * h;
-    uint32_t np = 0;  // survivors of this lane (acc holds TAGGED bounds, mn their minimum)
+    // (measured alternative: all sixteen compares first, then a scalar loop over the registers with survivors and a
+    // switch to read them -- 1320 instead of 1130 cycles per entry, C2 2.91 instead of 2.78 ms)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) np += acc[r] < tau ? 1u : 0u;
-#ifdef PN_DIAG_BF_COUNT
-    const unsigned long long t1_ = bf_stamp();
-#endif
-    if (!__any(np > 1u)) {
-        // steady state: a lane has at most one survivor, its minimum, whose tag is the register number
-        const bool p = mn < tau;
-        const uint32_t pp = p ? 1u : 0u;
-        const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
-        const uint32_t other = h ? sw[0] : sw[1];  // the other half's lane of the same query
-        if (p) {
-            const uint32_t r = __float_as_uint(mn) & 15u;
-            const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
-            // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
-            ceq[o] = make_uint2(f2s(mn), rowb + (r & 3u) + 8u * (r >> 2));
-        }
-        BF_COUNT(1, pp);
-        cnt += pp + other;
-        ns += 1;
-    } else {
-        // general case: one short block per register that holds a survivor in SOME lane
-        uint32_t wor = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wor |= (__any(acc[r] < tau) ? 1u : 0u) << r;
-        while (wor) {
-            const int r = __builtin_ctz(wor);
-            wor &= wor - 1;
-            const float v = acc[r];  // r is wave-uniform: indexed register read
-            const bool p = v < tau;
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        const bool p = v < t;
+        if (__any(p)) {
             const uint32_t pp = p ? 1u : 0u;
             const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
-            const uint32_t other = h ? sw[0] : sw[1];
+            const uint32_t other = h ? sw[0] : sw[1];  // the other half's lane of the same query
             if (p) {
-                const uint32_t o = cnt + (h ? other : 0u);
+                const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
+                // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
                 ceq[o] = make_uint2(f2s(v), rowb + (uint32_t)((r & 3) + 8 * (r >> 2)));
             }
-            BF_COUNT(1, pp);
+            BF_COUNT(1, __popcll(__ballot(p)));
             cnt += pp + other;
             ns += 1;
         }
     }
-#ifdef PN_DIAG_BF_COUNT
-    const unsigned long long t2_ = bf_stamp();
-#endif
     if (RAD) {
         if (cnt > CAP - 32) {  // would need compacting: overflow, and nothing more is stored
             cnt = CAP + 1;
@@ -439,6 +533,9 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
     }
     unsigned long long need = __ballot(h == 0 && cnt > CAP - 32);
     if (need) {
+#ifdef PN_DIAG_BF_COUNT
+        tc_ = bf_stamp();
+#endif
         // the entries were stored by both halves of the wave: they must have left before they are read back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ns = 0;
@@ -447,7 +544,7 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
             need &= need - 1;
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
             uint32_t T, nn;
-            if (lane == 0) BF_COUNT(2, 1);
+            BF_COUNT(2, 1);
             bf_compact<M>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
             if (jq == j) {
                 tau = s2f(T);
@@ -459,12 +556,8 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
 #ifdef PN_DIAG_BF_COUNT
     {
         const unsigned long long t3_ = bf_stamp();
-        if (lane == 0) {
-            BF_COUNT(3, t3_ - t0_);
-            BF_COUNT(5, t1_ - t0_);
-            BF_COUNT(6, t2_ - t1_);
-            BF_COUNT(7, t3_ - t2_);
-        }
+        BF_COUNT(3, t3_ - t0_);
+        if (tc_) BF_COUNT(4, t3_ - tc_);
     }
 #endif
 }
@@ -495,7 +588,7 @@ __device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
 }
 
 // cand: [nseg][nq_pad][64*M] (key, row) pairs; ccnt/ctau: [nseg][nq_pad], pre-initialised to 0 / sortable(+inf)
-template <int KS, int M, bool RAD>
+template <int KS, int M, bool RAD, bool CI>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
                                                              uint32_t kp, uint2 *__restrict__ cand,
@@ -514,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jq = lane & 31, h = lane >> 5;
+    BF_DBG_DECL;
 
     // Work list: (query tile, row part, tile within the part) in that order; `split` row parts per query tile
     // (1 unless the host wants more, shorter segments per query: see bf16_slots in index.hip), tps tiles each
@@ -564,6 +658,9 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         const uint32_t seg = part * seg_per_part + (uint32_t)(w - wf);
         const size_t q0 = (size_t)qt * kBQ + (size_t)wave * 64;  // first query of this wave
         const size_t cell0 = (size_t)seg * nq_pad + q0;          // its (segment, query) cell
+#if defined(PN_DIAG_BF_COUNT)
+        const unsigned long long trun0_ = bf_stamp();
+#endif
 
         // ---- per-run state: B fragments, thresholds and counts in registers
         bf16x8 b0[KS], b1[KS];
@@ -636,12 +733,17 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                     pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
                     pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
                 }
+                f32x16 c0 = x00, c1 = x00;  // (placeholders unless CI)
+                if (CI) {
+                    c0 = bf_cinit<CP>(tb, 0, h);
+                    c1 = bf_cinit<CP>(tb, 1, h);
+                }
                 if (rt + 1 < rt0 + t_scout) dma_tile(rt + 1, cs ^ 1);
                 float m0, m1;
-                bf_chain<KS, false>(arow0, pre0, b0, b1, x00, x01, x10, x11, m0, m1);
+                bf_chain<KS, CI>(arow0, pre0, b0, b1, c0, x00, x01, x10, x11, m0, m1);
                 insert(s0, m0);
                 insert(s1, m1);
-                bf_chain<KS, false>(arow1, pre1, b0, b1, x10, x11, x00, x01, m0, m1);
+                bf_chain<KS, CI>(arow1, pre1, b0, b1, c1, x10, x11, x00, x01, m0, m1);
                 insert(s0, m0);
                 insert(s1, m1);
                 __syncthreads();
@@ -694,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         //   chain(block 1) -> a1x while the VALU takes the minima of a0x; barrier
         f32x16 a00, a01, a10, a11;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // finite: a tag on +inf would make a NaN
+        for (int r = 0; r < 16; ++r) {  // "nothing here yet": above every threshold
             a00[r] = 3.0e38f;
             a01[r] = 3.0e38f;
             a10[r] = 3.0e38f;
@@ -712,26 +814,32 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
                 pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
             }
+            f32x16 c0 = a00, c1 = a00;  // (placeholders unless CI)
+            if (CI) {
+                c0 = bf_cinit<CP>(tb, 0, h);
+                c1 = bf_cinit<CP>(tb, 1, h);
+            }
             if (rt + 1 < rt1) dma_tile(rt + 1, cur ^ 1);
             ns = 0;
             if (__any(p0 < tau0 || p1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP;
-                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
             float m0, m1;
-            bf_chain<KS, true>(arow0, pre0, b0, b1, a00, a01, a10, a11, m0, m1);
+            bf_chain<KS, CI>(arow0, pre0, b0, b1, c0, a00, a01, a10, a11, m0, m1);
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
-                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
-            bf_chain<KS, true>(arow1, pre1, b0, b1, a10, a11, a00, a01, p0, p1);
+            bf_chain<KS, CI>(arow1, pre1, b0, b1, c1, a10, a11, a00, a01, p0, p1);
             // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
 #if defined(PN_DIAG_BF_COUNT)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the diagnostic atomics are not counted in ns
-#elif !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
+            const unsigned long long tb0_ = bf_stamp();
+#endif
+#if !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
             bf_wait_dma(ns);
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -739,13 +847,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
+#if defined(PN_DIAG_BF_COUNT)
+            BF_COUNT(6, bf_stamp() - tb0_);
+#endif
         }
         {  // drain: both blocks of the last tile
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                a10[i] = __uint_as_float((__float_as_uint(a10[i]) & 0xFFFFFFF0u) | (uint32_t)i);
-                a11[i] = __uint_as_float((__float_as_uint(a11[i]) & 0xFFFFFFF0u) | (uint32_t)i);
-            }
             float m0 = a10[0], m1 = a11[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
@@ -753,14 +859,17 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m1 = fminf(m1, a11[i]);
             }
             uint32_t row0 = (rt1 - 1) * kBP;
-            if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-            if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+            if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             row0 += 32;
-            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
-            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
         }
         // ---- end of run: at most kp candidates per query stay; publish count and threshold
         {
+#if defined(PN_DIAG_BF_COUNT)
+            const unsigned long long te0_ = bf_stamp();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long need = RAD ? 0ull : __ballot(h == 0 && cnt0 > kp);
             while (need) {
@@ -790,6 +899,14 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 ccnt[cell0 + 32 + jq] = cnt1;
                 ctau[cell0 + 32 + jq] = f2s(tau1);
             }
+#if defined(PN_DIAG_BF_COUNT)
+            {
+                const unsigned long long te1_ = bf_stamp();
+                BF_COUNT(5, te1_ - te0_);
+                BF_COUNT(7, te1_ - trun0_);
+            }
+            BF_DBG_FLUSH(lane);
+#endif
         }
         u0 = run_end;
     }
@@ -805,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 //    64 LDS-DMA pieces of the next stage (waves 0-3 the corpus piece, 4-7 the query piece) right behind the one
 //    barrier per chunk; the query chunks are re-streamed for every row tile from L2, where the XCD-aware block order
 //    below keeps them (and shares every corpus tile between the workgroups of an XCD);
-//  * after the last chunk of a row tile the eight blocks are tagged, reduced and filtered exactly as in the narrow
+//  * after the last chunk of a row tile the eight blocks are reduced and filtered exactly as in the narrow
 //    kernel (bf_slow, bf_compact); the other wave of the SIMD keeps the matrix pipe busy meanwhile;
 //  * the two row halves of a workgroup are two SEGMENTS of the query (own buffers, own thresholds); the partition is
 //    the balanced persistent one of the narrow kernel (equal slices of the (query tile, row tile) list, one
@@ -830,6 +947,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jq = lane & 31, h = lane >> 5;
     const int qg = wave & 3, rh = wave >> 2;
+    BF_DBG_DECL;
 
     // Logical workgroup: hardware block b runs on XCD b % 8.  Giving each XCD a contiguous range of logical
     // workgroups puts a few query tiles' row ranges on one L2 (their chunks are re-read from there) and lets
@@ -1060,11 +1178,6 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
         contract(rt, rt1);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[rb][0][i] = __uint_as_float((__float_as_uint(acc[rb][0][i]) & 0xFFFFFFF0u) | (uint32_t)i);
-                acc[rb][1][i] = __uint_as_float((__float_as_uint(acc[rb][1][i]) & 0xFFFFFFF0u) | (uint32_t)i);
-            }
             float m0 = acc[rb][0][0], m1 = acc[rb][1][0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
@@ -1073,9 +1186,9 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             }
             const uint32_t row0 = rt * (uint32_t)kWR + (uint32_t)(rh * 128 + rb * 32);
             if (__any(m0 < tau0))
-                bf_slow<M, RAD>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns);
+                bf_slow<M, RAD>(acc[rb][0], tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
             if (__any(m1 < tau1))
-                bf_slow<M, RAD>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns);
+                bf_slow<M, RAD>(acc[rb][1], tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
         }
     }
     // ---- end of run: at most kp candidates per query stay; publish count and threshold
@@ -1124,21 +1237,22 @@ extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int bf16_ks_for(int dim) { return bf16_steps(dim); }
+int bf16_ks_for(int dim, bool ci) { return bf16_steps_for(dim, ci); }
+bool bf16_ci_candidate(int dim) { return bf16_ci_dim(dim); }
 // D <= 128: operand-stationary kernel (bf16_filter_kernel); 128 < D <= 1024: K-chunked kernel (bf16_wide_kernel).
 // The accumulation-error allowance g = 2^-13 was checked against chains of up to 65 MFMA steps (tests/test_gpu_bf16.py).
 bool bf16_supported(int dim) { return dim >= 1 && dim <= 1024; }
 bool bf16_is_wide(int dim) { return dim > 128; }
-size_t bf16_image_bytes(size_t n, int dim) {
+size_t bf16_image_bytes(size_t n, int dim, bool ci) {
     if (bf16_is_wide(dim))
         return (n + kWR - 1) / kWR * bf16_wide_tile_bytes(dim);
     const size_t n_tiles = (n + kBP - 1) / kBP;
-    return n_tiles * (size_t)kBP * (size_t)(2 * bf16_ks_for(dim) + 1) * 16;
+    return n_tiles * (size_t)kBP * (size_t)(2 * bf16_ks_for(dim, ci) + 1) * 16;
 }
-size_t bf16_query_bytes(size_t nq_pad, int dim) {
+size_t bf16_query_bytes(size_t nq_pad, int dim, bool ci) {
     if (bf16_is_wide(dim))
         return (nq_pad + kWR - 1) / kWR * bf16_wide_tile_bytes(dim);
-    return nq_pad * (size_t)bf16_ks_for(dim) * 32;
+    return nq_pad * (size_t)bf16_ks_for(dim, ci) * 32;
 }
 #ifdef PN_DIAG_BF_CAP
 int bf16_cap_for(int kp) { return kp + 32 <= PN_DIAG_BF_CAP ? PN_DIAG_BF_CAP : 256; }
@@ -1171,28 +1285,37 @@ hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld,
     return hipGetLastError();
 }
 
+hipError_t launch_bf16_row_stats(const float *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(bf16_row_stats_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld, out4);
+    return hipGetLastError();
+}
+
 hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
-                                   uint32_t *bad, hipStream_t s) {
+                                   uint32_t *bad, bool ci, hipStream_t s) {
     const bool wide = bf16_is_wide(dim);
+    if (wide && ci) return hipErrorInvalidValue;
     const size_t rows = wide ? (n + kWR - 1) / kWR * kWR : (n + kBP - 1) / kBP * kBP;
     hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
-                       bf16_ks_for(dim), static_cast<uint16_t *>(img), rows, bad, wide ? 1 : 0);
+                       bf16_ks_for(dim, ci), static_cast<uint16_t *>(img), rows, bad, wide ? 1 : 0, ci ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
-                                    void *B, double *qn, uint32_t *qbad, hipStream_t s) {
+                                    void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
+                                    hipStream_t s) {
     hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
-                       dim, ld, bf16_ks_for(dim), static_cast<uint16_t *>(B), qn, qbad, bf16_is_wide(dim) ? 1 : 0);
+                       dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, bf16_is_wide(dim) ? 1 : 0,
+                       ci ? 1 : 0, bmax, dmax);
     return hipGetLastError();
 }
 
-template <int KS, int M, bool RAD>
+template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, hipStream_t s) {
     const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
-    auto kern = bf16_filter_kernel<KS, M, RAD>;
+    auto kern = bf16_filter_kernel<KS, M, RAD, CI>;
     static LdsAttrOnce lds_attr;  // per instantiation
     {
         const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
@@ -1204,24 +1327,24 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
     return hipGetLastError();
 }
 
-template <int KS>
+template <int KS, bool CI>
 static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, bool radius, float *scout_out, hipStream_t s) {
     if (radius)
-        return cb.cap == 256 && tau_init ? launch_bf16_t<KS, 4, true>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp,
-                                                                      scout_max, tau_init, nullptr, s)
+        return cb.cap == 256 && tau_init ? launch_bf16_t<KS, 4, true, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split,
+                                                                          spp, scout_max, tau_init, nullptr, s)
                                          : hipErrorInvalidValue;
     switch (cb.cap) {
         case 64:
-            return launch_bf16_t<KS, 1, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
-                                               scout_out, s);
+            return launch_bf16_t<KS, 1, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
+                                                   tau_init, scout_out, s);
         case 128:
-            return launch_bf16_t<KS, 2, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
-                                               scout_out, s);
+            return launch_bf16_t<KS, 2, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
+                                                   tau_init, scout_out, s);
         case 256:
-            return launch_bf16_t<KS, 4, false>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max, tau_init,
-                                               scout_out, s);
+            return launch_bf16_t<KS, 4, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
+                                                   tau_init, scout_out, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1235,9 +1358,9 @@ int bf16_segments(size_t q_tiles, int n_wg, int split) {
 
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
-                              hipStream_t s) {
+                              bool ci, hipStream_t s) {
     if (!bf16_supported(dim) || bf16_is_wide(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
-        cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0)
+        cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0 || (ci && !bf16_ci_dim(dim)))
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kBP - 1) / kBP);
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kBQ);
@@ -1248,17 +1371,21 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     const bool aligned = split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0;
     if (cb.nseg < (aligned ? n_wg / (int)q_tiles : (int)(spp * split))) return hipErrorInvalidValue;
     const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
-    switch (bf16_ks_for(dim)) {
-        case 2: return launch_bf16_m<2>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 3: return launch_bf16_m<3>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 4: return launch_bf16_m<4>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 5: return launch_bf16_m<5>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 6: return launch_bf16_m<6>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 7: return launch_bf16_m<7>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 8: return launch_bf16_m<8>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
-        case 9: return launch_bf16_m<9>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+#define PN_BF_CASE(K, C) \
+    case K: return launch_bf16_m<K, C>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+    if (ci) {
+        switch (bf16_ks_for(dim, true)) {
+            PN_BF_CASE(2, true) PN_BF_CASE(3, true) PN_BF_CASE(4, true) PN_BF_CASE(5, true) PN_BF_CASE(6, true)
+            PN_BF_CASE(7, true) PN_BF_CASE(8, true)
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (bf16_ks_for(dim, false)) {
+        PN_BF_CASE(2, false) PN_BF_CASE(3, false) PN_BF_CASE(4, false) PN_BF_CASE(5, false) PN_BF_CASE(6, false)
+        PN_BF_CASE(7, false) PN_BF_CASE(8, false) PN_BF_CASE(9, false)
         default: return hipErrorInvalidValue;
     }
+#undef PN_BF_CASE
 }
 
 // Shared scout (few queries, many segments per query): a scout-only launch leaves, per (segment, query) cell and
@@ -1300,16 +1427,14 @@ int bf16_scout_list() { return kScoutList; }
 
 // radius queries: per-query threshold of the filter.  A row can only be within the radius when its exact squared
 // distance is below tau_r (computed by the host with the rounding allowances of select.hip's proof), hence when
-// L' < tau_r - |q|^2_down.  out[q] = sortable key of that bound, widened by the tag tolerance, rounded up to f32 and
+// L' < tau_r - |q|^2_down.  out[q] = sortable key of that bound, widened by a 2^-18 margin, rounded up to f32 and
 // one step beyond (strict <).
 __global__ void bf16_radius_tau_kernel(const double *__restrict__ qn, size_t nq_pad, double tau_r,
                                        uint32_t *__restrict__ out) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    // The kernel compares TAGGED bounds (low four mantissa bits = register number, bf_chain<EMB>): a tagged value is
-    // within 15 ulp = |L'| 2^-19 of the bound L' itself.  A row within the radius has L' < t; widening the threshold
-    // by |t| 2^-18 keeps its tagged bound below it in every sign case (L' >= 0: L'(1 + 2^-19) < t (1 + 2^-19);
-    // L' < 0 <= t: tagged values of negative bounds are negative; L', t < 0: L'(1 - 2^-19) < t (1 - 2^-19)).
+    // A margin of |t| 2^-18 on top of the rounding below (round 1's kernels compared bounds whose low four mantissa
+    // bits carried a row tag; the margin was sized for that and is kept: it costs a handful of exact checks).
     double t = tau_r - qn[q];
     t += fabs(t) * 3.814697265625e-06;
     float f = (float)t;
@@ -1326,7 +1451,7 @@ hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r,
 
 // debug / test entry: L'(q, p) for every pair of a small problem, straight from the MFMA (one wave per
 // 32 x 32 block), so tests can check L' <= |q-p|^2 - |q|^2 against f64 and measure the accumulation error.
-template <int KS>
+template <int KS, bool CI>
 __global__ __launch_bounds__(64) void bf16_bound_kernel(const char *__restrict__ img, const u32x4 *__restrict__ Bq,
                                                         uint32_t n_rows, uint32_t nq, float *__restrict__ out) {
     constexpr int C = 2 * KS, CP = C + 1;
@@ -1338,6 +1463,7 @@ __global__ __launch_bounds__(64) void bf16_bound_kernel(const char *__restrict__
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (CI) acc = bf_cinit<CP>(img + (size_t)(rb * 32 / kBP) * kBP * CP * 16, (int)((rb * 32 % kBP) / 32), h);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const u32x4 av = *reinterpret_cast<const u32x4 *>(arow + 32 * ks);
@@ -1356,27 +1482,35 @@ __global__ __launch_bounds__(64) void bf16_bound_kernel(const char *__restrict__
 __global__ void bf16_wide_bound_kernel(const char *__restrict__ img, const char *__restrict__ Bimg, uint32_t nkc,
                                        uint32_t tile_bytes, uint32_t has_x, uint32_t n_rows, uint32_t nq,
                                        float *__restrict__ out);
-hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
+hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out, bool ci,
                              hipStream_t s) {
     // img covers round_up(n_rows, 64) rows and B round_up(nq, 32) queries at least
     const dim3 grid((unsigned)((n_rows + 31) / 32), (unsigned)((nq + 31) / 32));
     const char *im = static_cast<const char *>(img);
     if (bf16_is_wide(dim)) {  // img covers round_up(n_rows, 256) rows, B round_up(nq, 256) queries
-        if (!bf16_supported(dim)) return hipErrorInvalidValue;
+        if (!bf16_supported(dim) || ci) return hipErrorInvalidValue;
         hipLaunchKernelGGL(bf16_wide_bound_kernel, grid, dim3(64), 0, s, im, static_cast<const char *>(B),
                            (uint32_t)bf16_wide_nkc(dim), (uint32_t)bf16_wide_tile_bytes(dim),
                            bf16_wide_has_x(dim) ? 1u : 0u, (uint32_t)n_rows, (uint32_t)nq, out);
         return hipGetLastError();
     }
     const u32x4 *b = static_cast<const u32x4 *>(B);
-#define PN_BOUND_CASE(K)                                                                                       \
-    case K:                                                                                                    \
-        hipLaunchKernelGGL(bf16_bound_kernel<K>, grid, dim3(64), 0, s, im, b, (uint32_t)n_rows, (uint32_t)nq, out); \
+#define PN_BOUND_CASE(K, C)                                                                                       \
+    case K:                                                                                                       \
+        hipLaunchKernelGGL((bf16_bound_kernel<K, C>), grid, dim3(64), 0, s, im, b, (uint32_t)n_rows, (uint32_t)nq, out); \
         break;
-    switch (bf16_ks_for(dim)) {
-        PN_BOUND_CASE(2) PN_BOUND_CASE(3) PN_BOUND_CASE(4) PN_BOUND_CASE(5) PN_BOUND_CASE(6) PN_BOUND_CASE(7)
-        PN_BOUND_CASE(8) PN_BOUND_CASE(9)
-        default: return hipErrorInvalidValue;
+    if (ci) {
+        switch (bf16_ks_for(dim, true)) {
+            PN_BOUND_CASE(2, true) PN_BOUND_CASE(3, true) PN_BOUND_CASE(4, true) PN_BOUND_CASE(5, true)
+            PN_BOUND_CASE(6, true) PN_BOUND_CASE(7, true) PN_BOUND_CASE(8, true)
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (bf16_ks_for(dim, false)) {
+            PN_BOUND_CASE(2, false) PN_BOUND_CASE(3, false) PN_BOUND_CASE(4, false) PN_BOUND_CASE(5, false)
+            PN_BOUND_CASE(6, false) PN_BOUND_CASE(7, false) PN_BOUND_CASE(8, false) PN_BOUND_CASE(9, false)
+            default: return hipErrorInvalidValue;
+        }
     }
 #undef PN_BOUND_CASE
     return hipGetLastError();

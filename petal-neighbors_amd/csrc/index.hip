@@ -151,6 +151,8 @@ struct pn_index {
     float *d_mu = nullptr;   // translation vector of the bf16 tier: the corpus mean per dimension, or zero
     bool centered = false;   // d_mu != 0: translating shrinks the squared norms at least 16x
     bool bf16_ok = false;
+    bool bf16_ci = false;    // "norm in the accumulator" image layout (bf16_filter.hip, bf16_ci_dim)
+    double bf16_bmax = 0.0, bf16_dmax = 0.0;  // corpus-wide maxima of the bound's per-row constants (CI layout)
     int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
     hipStream_t stream = nullptr;  // construction
     unsigned long long *d_stats = nullptr;  // running device counters {fallback queries, candidates, evaluations}
@@ -170,6 +172,7 @@ struct pn_index {
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
+        HostTree *tree = nullptr;  // the reference's ball tree, built on first use of the introspection API (tree.cpp)
     };
     mutable Shared sh;
 };
@@ -242,7 +245,6 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         ix->mfma_ok = (h_flag == 0) && mfma_supported((int)ix->dim, ix->ld) && ix->n < 0xFFFFFFF0ull;
         ix->bf16_ok = false;
         if (bf16_supported((int)ix->dim) && ix->n < 0xFFFFFFF0ull && ix->n >= 64) {
-            HIPCHK(hipMalloc(&ix->d_img, bf16_image_bytes(ix->n, (int)ix->dim)));
             uint32_t *d_bad = nullptr;
             HIPCHK(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
             HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s));
@@ -277,8 +279,28 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
                 HIPCHK(hipMemcpyAsync(ix->d_mu, h_mu.data(), ix->dim * sizeof(float), hipMemcpyHostToDevice, s));
                 HIPCHK(hipStreamSynchronize(s));
             }
+            ix->bf16_ci = false;
+#ifndef PN_DIAG_NO_CI
+            if (bf16_ci_candidate((int)ix->dim)) {
+                // the extra columns would cost an MFMA step of their own: drop them when the corpus-wide maxima of
+                // the bound's per-row constants are close to their means (homogeneous row norms)
+                double *d_st = nullptr, h_st[4] = {0, 0, 0, 0};
+                HIPCHK(hipMalloc((void **)&d_st, sizeof h_st));
+                HIPCHK(hipMemsetAsync(d_st, 0, sizeof h_st, s));
+                HIPCHK(launch_bf16_row_stats((const float *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, d_st, s));
+                HIPCHK(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                (void)hipFree(d_st);
+                const double bmean = h_st[2] / (double)ix->n, dmean = h_st[3] / (double)ix->n;
+                ix->bf16_ci = h_st[0] > 0.0 && h_st[1] > 0.0 && h_st[0] <= 1.3 * bmean && h_st[1] <= 1.3 * dmean &&
+                              h_st[0] < 1e30 && h_st[1] < 1e30;
+                ix->bf16_bmax = h_st[0];
+                ix->bf16_dmax = h_st[1];
+            }
+#endif
+            HIPCHK(hipMalloc(&ix->d_img, bf16_image_bytes(ix->n, (int)ix->dim, ix->bf16_ci)));
             HIPCHK(launch_bf16_pack_corpus((const float *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, ix->d_img,
-                                           d_bad, s));
+                                           d_bad, ix->bf16_ci, s));
             uint32_t h_bad = 0;
             HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -423,6 +445,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_norm) (void)hipFree(ix->d_norm);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    if (ix->sh.tree) host_tree_free(ix->sh.tree);
     delete ix;
 }
 
@@ -570,6 +593,8 @@ extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
     out->device = ix->device;
     out->mfma_eligible = ix->mfma_ok ? 1 : 0;
     out->bf16_eligible = ix->bf16_ok ? 1 : 0;
+    out->bf16_layout = !ix->bf16_ok ? 0 : ix->bf16_ci ? 2 : 1;
+    out->reserved = 0;
     return PN_OK;
 }
 
@@ -1066,7 +1091,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     const int n_wg = plan.n_wg, cap = plan.cap, nseg = plan.nseg;
     const size_t kp = (size_t)plan.kp;
     const size_t cells = (size_t)nseg * nq_pad, slots = cells * (size_t)cap;
-    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim, ix->bf16_ci)));
     PNCHK(ws.w_qn.ensure(nq_pad * sizeof(double)));
     PNCHK(ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)));
     PNCHK(ws.w_keys.ensure(slots * 2 * sizeof(uint32_t)));  // (key, row) pairs
@@ -1076,7 +1101,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     PNCHK(ws.w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
     HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                    (uint32_t *)ws.w_qbad.p, s));
+                                    (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_keys.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
     if (!plan.aligned) {  // cells without a writer must read "empty" (an aligned partition writes every cell)
         HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -1099,7 +1124,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
                                            plan.scout_tiles, nullptr, false, (float *)ws.w_lists.p, s));
         else
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
-                                      nullptr, false, (float *)ws.w_lists.p, s));
+                                      nullptr, false, (float *)ws.w_lists.p, ix->bf16_ci, s));
         if (prof) HIPCHK(hipEventRecord(rec->ev[4], s));
         HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s));
         if (prof) HIPCHK(hipEventRecord(rec->ev[5], s));
@@ -1108,13 +1133,13 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
                                            (const uint32_t *)ws.w_seed.p, false, nullptr, s));
         else
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, 0,
-                                      (const uint32_t *)ws.w_seed.p, false, nullptr, s));
+                                      (const uint32_t *)ws.w_seed.p, false, nullptr, ix->bf16_ci, s));
     } else if (plan.wide) {
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg,
                                        plan.scout_max, nullptr, false, nullptr, s));
     } else {
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, plan.split,
-                                  plan.scout_max, nullptr, false, nullptr, s));
+                                  plan.scout_max, nullptr, false, nullptr, ix->bf16_ci, s));
     }
     if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
@@ -1345,7 +1370,7 @@ extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq,
         const size_t nq_pad = round_up(nq, (size_t)256);
         rc = PN_ERR_DEVICE;
         if (ws.w_q.ensure(nq_pad * ix->ld * sizeof(float)) != PN_OK ||
-            ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)) != PN_OK ||
+            ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim, ix->bf16_ci)) != PN_OK ||
             ws.w_qn.ensure(nq_pad * sizeof(double)) != PN_OK || ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)) != PN_OK)
             break;
         if (hipMalloc((void **)&d_out, nq * n_rows * sizeof(float)) != hipSuccess) {
@@ -1355,8 +1380,8 @@ extern "C" int pn_bf16_bounds_f32(const pn_index *ix, const float *q, size_t nq,
         float *Qp = (float *)ws.w_q.p;
         if (launch_pack_rows_f32(d_q, nq, ix->dim, q_cols, Qp, nq_pad, ix->ld, s) != hipSuccess ||
             launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                     (uint32_t *)ws.w_qbad.p, s) != hipSuccess ||
-            launch_bf16_bound(ix->d_img, ws.w_bq.p, n_rows, nq, (int)ix->dim, d_out, s) != hipSuccess ||
+                                     (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s) != hipSuccess ||
+            launch_bf16_bound(ix->d_img, ws.w_bq.p, n_rows, nq, (int)ix->dim, d_out, ix->bf16_ci, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess ||
             hipMemcpy(bounds_out, d_out, nq * n_rows * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
             (qnorm_out && hipMemcpy(qnorm_out, ws.w_qn.p, nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) ||
@@ -1599,7 +1624,7 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
     // below it (same allowances as the k-NN proof)
     const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
     if (!(t < 1e37)) return PN_OK;  // let the exact engine decide
-    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim)));
+    PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim, ix->bf16_ci)));
     PNCHK(ws.w_qn.ensure(nq_pad * sizeof(double)));
     PNCHK(ws.w_qbad.ensure(nq_pad * sizeof(uint32_t)));
     PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
@@ -1614,7 +1639,7 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
     HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
     HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                    (uint32_t *)ws.w_qbad.p, s));
+                                    (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
     PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
     HIPCHK(launch_compact_flags((const uint32_t *)ws.w_qbad.p, (int)nq, (uint32_t *)ws.w_gsel.p, d_misc + 1, s));
     HIPCHK(launch_bf16_radius_tau((const double *)ws.w_qn.p, nq_pad, t, (uint32_t *)ws.w_seed.p, s));
@@ -1624,7 +1649,7 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
                                        (const uint32_t *)ws.w_seed.p, true, nullptr, s));
     else
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
-                                  (const uint32_t *)ws.w_seed.p, true, nullptr, s));
+                                  (const uint32_t *)ws.w_seed.p, true, nullptr, ix->bf16_ci, s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                    (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
@@ -1804,6 +1829,118 @@ extern "C" int pn_pairwise_f32(const float *x, size_t n, size_t cols, ptrdiff_t 
 }
 extern "C" int pn_pairwise_f64(const double *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, double *out) {
     return pairwise_impl<double>(x, n, cols, row_stride, device, out);
+}
+
+// ---------------------------------------------------------------------------
+// tree introspection (src/ball_tree.rs:296-353): a host-side ball tree identical to the reference's, built lazily
+// ---------------------------------------------------------------------------
+static int tree_of(const pn_index *ix, const HostTree **out) {
+    if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    if (!ix->sh.tree) {
+        DeviceGuard g(ix->device);
+        if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
+        const size_t eb = (size_t)ix->elem_bytes, cols = ix->dim ? ix->dim : 1;
+        std::vector<unsigned char> host;
+        try {
+            host.resize(ix->n * cols * eb);
+        } catch (const std::bad_alloc &) {
+            return fail(PN_ERR_NOMEM, "host allocation of %zu rows failed", ix->n);
+        }
+        if (ix->dim)  // the index's own zero-padded copy of the points, rows back to their unpadded length
+            HIPCHK(hipMemcpy2D(host.data(), ix->dim * eb, ix->d_pts, ix->ld * eb, ix->dim * eb, ix->n, hipMemcpyDeviceToHost));
+        ix->sh.tree = host_tree_build(host.data(), ix->n, ix->dim, ix->elem_bytes);
+        if (!ix->sh.tree) return fail(PN_ERR_NOMEM, "ball tree of %zu points: out of memory", ix->n);
+    }
+    *out = ix->sh.tree;
+    return PN_OK;
+}
+static int tree_node(const pn_index *ix, uint64_t node, const HostTree **t) {
+    PNCHK(tree_of(ix, t));
+    if (node >= host_tree_num_nodes(*t))  // the reference panics (slice index out of bounds)
+        return fail(PN_ERR_INVALID, "node %llu out of range (the tree has %zu nodes)", (unsigned long long)node,
+                    host_tree_num_nodes(*t));
+    return PN_OK;
+}
+extern "C" int pn_tree_num_nodes(const pn_index *ix, uint64_t *out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    const HostTree *t = nullptr;
+    PNCHK(tree_of(ix, &t));
+    *out = host_tree_num_nodes(t);
+    return PN_OK;
+}
+extern "C" int pn_tree_children_of(const pn_index *ix, uint64_t node, int *is_some, uint64_t *left, uint64_t *right) {
+    if (!is_some || !left || !right) return fail(PN_ERR_INVALID, "NULL argument");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, node, &t));
+    uint64_t s, e;
+    int leaf;
+    host_tree_node(t, node, &s, &e, &leaf);
+    *is_some = leaf ? 0 : 1;
+    *left = 2 * node + 1;
+    *right = 2 * node + 2;
+    return PN_OK;
+}
+extern "C" int pn_tree_points_of(const pn_index *ix, uint64_t node, const uint64_t **idx, uint64_t *count) {
+    if (!idx || !count) return fail(PN_ERR_INVALID, "NULL argument");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, node, &t));
+    uint64_t s, e;
+    int leaf;
+    host_tree_node(t, node, &s, &e, &leaf);
+    *idx = host_tree_idx(t) + s;
+    *count = e - s;
+    return PN_OK;
+}
+extern "C" int pn_tree_radius_of_f32(const pn_index *ix, uint64_t node, float *out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    if (ix && ix->elem_bytes != 4) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, node, &t));
+    *out = (float)host_tree_radius(t, node);
+    return PN_OK;
+}
+extern "C" int pn_tree_radius_of_f64(const pn_index *ix, uint64_t node, double *out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    if (ix && ix->elem_bytes != 8) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, node, &t));
+    *out = host_tree_radius(t, node);
+    return PN_OK;
+}
+extern "C" int pn_tree_compare_nodes(const pn_index *ix, uint64_t x, uint64_t y, int *ordering) {
+    if (!ordering) return fail(PN_ERR_INVALID, "ordering is NULL");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, x, &t));
+    PNCHK(tree_node(ix, y, &t));
+    *ordering = host_tree_compare(t, x, y);
+    return PN_OK;
+}
+extern "C" int pn_tree_node_distance_lower_bound_f32(const pn_index *ix, uint64_t n1, uint64_t n2, float *out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    if (ix && ix->elem_bytes != 4) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, n1, &t));
+    PNCHK(tree_node(ix, n2, &t));
+    *out = (float)host_tree_lower_bound(t, n1, n2);
+    return PN_OK;
+}
+extern "C" int pn_tree_node_distance_lower_bound_f64(const pn_index *ix, uint64_t n1, uint64_t n2, double *out) {
+    if (!out) return fail(PN_ERR_INVALID, "out is NULL");
+    if (ix && ix->elem_bytes != 8) return fail(PN_ERR_INVALID, "index element type mismatch");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, n1, &t));
+    PNCHK(tree_node(ix, n2, &t));
+    *out = host_tree_lower_bound(t, n1, n2);
+    return PN_OK;
+}
+// test hook of the above: the centroid of a node (the reference keeps it private; tests compare it with the oracle's)
+extern "C" int pn_tree_centroid_of(const pn_index *ix, uint64_t node, void *out_dim_elems) {
+    if (!out_dim_elems) return fail(PN_ERR_INVALID, "out is NULL");
+    const HostTree *t = nullptr;
+    PNCHK(tree_node(ix, node, &t));
+    memcpy(out_dim_elems, host_tree_centroid(t, node), ix->dim * (size_t)ix->elem_bytes);
+    return PN_OK;
 }
 
 // ---------------------------------------------------------------------------

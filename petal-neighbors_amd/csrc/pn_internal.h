@@ -175,18 +175,25 @@ hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, con
 // ---- bf16_filter.hip: first-tier filter (bf16 MFMA lower bound of |q-p|^2 - |q|^2), D <= 128
 bool bf16_supported(int dim);
 bool bf16_is_wide(int dim);  // 128 < D: K-chunked kernel (launch_bf16_wide_filter), images in the chunked layout
-int bf16_ks_for(int dim);
-size_t bf16_image_bytes(size_t n, int dim);        // corpus tile images
-size_t bf16_query_bytes(size_t nq_pad, int dim);   // packed query rows
+// ci: the "norm in the accumulator" layout (bf16_filter.hip, bf16_ci_dim): no extra columns, row norms as the
+// chain's initial value, the error products as a per-query constant folded into qn
+int bf16_ks_for(int dim, bool ci);
+bool bf16_ci_candidate(int dim);
+size_t bf16_image_bytes(size_t n, int dim, bool ci);        // corpus tile images
+size_t bf16_query_bytes(size_t nq_pad, int dim, bool ci);   // packed query rows
 int bf16_cap_for(int kp);                          // slots per (segment, query): 64 / 128 / 256
 int bf16_query_tile();                             // queries per workgroup (256)
 // mu: translation vector [dim]; sums: [dim + 1] per-dimension f64 sums of the corpus + the sum of all squares
 // (zeroed by the caller)
 hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
+// out4 (zeroed by the caller): max Bp, max Dp, sum Bp, sum Dp over the rows
+hipError_t launch_bf16_row_stats(const float *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
+                                 hipStream_t s);
 hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
-                                   uint32_t *bad, hipStream_t s);
+                                   uint32_t *bad, bool ci, hipStream_t s);
 hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
-                                    void *B, double *qn, uint32_t *qbad, hipStream_t s);
+                                    void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
+                                    hipStream_t s);
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);
@@ -196,7 +203,7 @@ int bf16_segments(size_t q_tiles, int n_wg, int split);
 // minima in scout_out[cell][2][bf16_scout_list()] (pre-filled with +inf by the caller)
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
-                              hipStream_t s);
+                              bool ci, hipStream_t s);
 // wide rows: n_wg persistent workgroups (one per CU) over equal slices of the (query tile, row tile) list;
 // cb.nseg >= bf16_wide_segments(q_tiles, n_wg) (a workgroup's two row halves are two segments); cells without a writer
 // must read "empty" unless n_wg is a multiple of q_tiles; scout_max in 256-row tiles
@@ -211,9 +218,23 @@ int bf16_scout_list();
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);
 hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);
 // diagnostic: out[q][row] = L'(q, row), q < nq, row < n_rows
-hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out,
+hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out, bool ci,
                              hipStream_t s);
 
+}  // namespace pn
+
+// ---- tree.cpp: the reference's ball tree, built on the host only when its introspection API is used
+namespace pn {
+struct HostTree;
+HostTree *host_tree_build(const void *pts, size_t n, size_t dim, int elem_bytes);  // nullptr: out of memory
+void host_tree_free(HostTree *h);
+size_t host_tree_num_nodes(const HostTree *h);
+const uint64_t *host_tree_idx(const HostTree *h);
+void host_tree_node(const HostTree *h, size_t node, uint64_t *start, uint64_t *end, int *is_leaf);
+double host_tree_radius(const HostTree *h, size_t node);
+const void *host_tree_centroid(const HostTree *h, size_t node);
+int host_tree_compare(const HostTree *h, size_t x, size_t y);
+double host_tree_lower_bound(const HostTree *h, size_t n1, size_t n2);
 }  // namespace pn
 
 // ---- index.hip, for the other translation units

@@ -178,7 +178,9 @@ struct pn_sharded {
     uint64_t per = 0;  // rows per shard = ceil(n_total / n_shards)
     int n_shards = 0;  // over all processes
     int world = 1;     // ranks of the communicator (GPUs)
+    int max_parts_per_dev = 1;  // most shards any GPU holds (1 with one process per GPU)
     bool rank_mode = false;
+    bool exchange_always = false;  // PN_OPT_EXCHANGE_ALWAYS
     std::vector<Part> parts;  // local ones
     // queries take a `const pn_sharded *` (BallTree queries take &self); what they touch below -- streams, exchange
     // buffers, the communicator -- is shared per-handle state, internally serialised by `mu`: one query at a time
@@ -282,6 +284,7 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
         sh->parts.push_back(p);
         sh->devs[p.dev_slot].parts.push_back(g);
     }
+    for (const Dev &d : sh->devs) sh->max_parts_per_dev = std::max(sh->max_parts_per_dev, (int)d.parts.size());
     if (rc == PN_OK) {
         std::vector<ncclComm_t> comms(distinct.size(), nullptr);
         ncclResult_t r = rccl().CommInitAll(comms.data(), (int)distinct.size(), distinct.data());
@@ -367,13 +370,25 @@ extern "C" int pn_sharded_info(const pn_sharded *sh, pn_sharded_info_t *out) {
     out->rank = sh->rank_mode ? sh->devs[0].comm_rank : 0;
     out->local_first_row = sh->parts.empty() ? 0 : sh->parts.front().lo;
     out->local_rows = 0;
-    for (const Part &p : sh->parts) out->local_rows += p.hi - p.lo;
+    out->mfma_eligible = out->bf16_eligible = 1;
+    for (const Part &p : sh->parts) {
+        out->local_rows += p.hi - p.lo;
+        pn_info pi{};
+        if (p.ix && pn_index_info(p.ix, &pi) == PN_OK) {
+            out->mfma_eligible &= pi.mfma_eligible;
+            out->bf16_eligible &= pi.bf16_eligible;
+        }
+    }
     return PN_OK;
 }
 
 extern "C" int pn_sharded_set_option(pn_sharded *sh, int option, int64_t value) {
     if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
     if (option == PN_OPT_INDEX_BASE) return set_error(PN_ERR_INVALID, "the index base of a shard is its first row");
+    if (option == PN_OPT_EXCHANGE_ALWAYS) {
+        sh->exchange_always = value != 0;
+        return PN_OK;
+    }
     for (Part &p : sh->parts)
         if (p.ix) SPN(pn_index_set_option(p.ix, option, value));
     return PN_OK;
@@ -402,69 +417,74 @@ extern "C" int pn_sharded_get_stats(const pn_sharded *sh, pn_stats *out, int res
 // ---------------------------------------------------------------------------
 // k-NN
 // ---------------------------------------------------------------------------
-// The local half of one chunk on one GPU: every local shard's top-kp into the packed buffer `set` (several shards on
-// this GPU: merged to one packed buffer first).  Enqueued on `s`.
+// The local half of one chunk on one GPU: every local shard's top-kp, merged when the GPU holds several shards, into
+// the packed buffer `set` with kd slots per query (kd = what one GPU can contribute at most).  Enqueued on `s`.
 static int enqueue_local(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
-                         size_t k, size_t kp, int set, hipStream_t s) {
-    const size_t words = packed_words(nq, kp);
+                         size_t k, size_t kp, size_t kd, int set, hipStream_t s) {
+    const size_t words = packed_words(nq, kd), pwords = packed_words(nq, kp);
     SPN(d.pack[set].ensure(words * 8));
     const size_t np = d.parts.size();
-    uint64_t *target = (uint64_t *)d.pack[set].p;
-    if (np > 1) {
-        SPN(d.lparts.ensure(np * words * 8));
-        target = (uint64_t *)d.lparts.p;
+    uint64_t *oi = (uint64_t *)d.pack[set].p;
+    float *od = reinterpret_cast<float *>(oi + nq * kd);
+    if (np == 1) {  // straight into the buffer the all-gather sends
+        const Part &p = sh->parts[d.parts[0]];
+        if (p.hi - p.lo < kd)  // absent slots: index ~0 (and a NaN distance) -- the merge kernel skips them
+            SHIP(hipMemsetAsync(oi, 0xFF, words * 8, s));
+        if (p.ix) SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kd ? k : kd, oi, od, kd, s));
+        return PN_OK;
     }
+    SPN(d.lparts.ensure(np * pwords * 8));
+    uint64_t *stage = (uint64_t *)d.lparts.p;
     for (size_t i = 0; i < np; ++i) {
         const Part &p = sh->parts[d.parts[i]];
-        uint64_t *pi = target + i * words;
+        uint64_t *pi = stage + i * pwords;
         float *pd = reinterpret_cast<float *>(pi + nq * kp);
-        const uint64_t rows = p.hi - p.lo;
-        if (rows < kp)  // absent slots: index ~0 (and a NaN distance) -- the merge kernel skips them
-            SHIP(hipMemsetAsync(pi, 0xFF, words * 8, s));
-        if (p.ix)
-            SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
+        if (p.hi - p.lo < kp) SHIP(hipMemsetAsync(pi, 0xFF, pwords * 8, s));
+        if (p.ix) SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
     }
-    if (np > 1) {
-        uint64_t *oi = (uint64_t *)d.pack[set].p;
-        float *od = reinterpret_cast<float *>(oi + nq * kp);
-        SPN(pn_merge_topk_device_f32((const uint64_t *)d.lparts.p, reinterpret_cast<const float *>((const uint64_t *)d.lparts.p + nq * kp),
-                                     np, words, 2 * words, nq, kp, kp, oi, od, d.device, s));
-    }
-    return PN_OK;
+    return pn_merge_topk_device_f32(stage, reinterpret_cast<const float *>(stage + nq * kp), np, pwords, 2 * pwords, nq, kp,
+                                    kd, oi, od, d.device, s);
 }
 
 // exchange + final merge of one chunk on one GPU, enqueued on `s`: one all-gather of the packed buffer, then the
 // (distance, index) merge of the world's parts into d_idx/d_dist [nq][k_out]
-static int enqueue_merge(const pn_sharded *sh, Dev &d, size_t nq, size_t kp, size_t k_out, int set, uint64_t *d_idx,
+static int enqueue_merge(const pn_sharded *sh, Dev &d, size_t nq, size_t kd, size_t k_out, int set, uint64_t *d_idx,
                          float *d_dist, hipStream_t s) {
-    const size_t words = packed_words(nq, kp);
+    const size_t words = packed_words(nq, kd);
     const uint64_t *g = (const uint64_t *)d.gathered[set].p;
-    return pn_merge_topk_device_f32(g, reinterpret_cast<const float *>(g + nq * kp), (size_t)sh->world, words, 2 * words, nq,
-                                    kp, k_out, d_idx, d_dist, d.device, s);
+    return pn_merge_topk_device_f32(g, reinterpret_cast<const float *>(g + nq * kd), (size_t)sh->world, words, 2 * words, nq,
+                                    kd, k_out, d_idx, d_dist, d.device, s);
 }
 
-static size_t k_part_of(const pn_sharded *sh, size_t k) {
+static size_t k_part_of(const pn_sharded *sh, size_t k) {  // slots per query a SHARD fills
     const uint64_t largest = std::min<uint64_t>(sh->per, sh->n_total);  // shard 0 is never smaller than another
     return (size_t)std::min<uint64_t>(k, largest ? largest : 1);
+}
+static size_t k_dev_of(const pn_sharded *sh, size_t k) {  // slots per query a GPU sends: the same on every rank
+    uint64_t most = (uint64_t)sh->max_parts_per_dev * sh->per;
+    if (most > sh->n_total) most = sh->n_total;
+    return (size_t)std::min<uint64_t>(k, most ? most : 1);
 }
 
 // rank mode (or one GPU): queries and results on this process's GPU, everything enqueued on `s`
 static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
                             size_t k, uint64_t *d_idx, float *d_dist, hipStream_t s) {
-    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k);
+    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k), kd = k_dev_of(sh, k);
     SetGuard g(d.device);
     if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+    if (sh->n_shards == 1 && !sh->exchange_always)  // one shard: nothing to exchange, straight into the caller's buffers
+        return query_device_strided_f32(sh->parts[0].ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, k_out, s);
     const size_t chunk = nq > kShardChunk ? kShardChunk : nq;
     const bool overlapped = nq > chunk;  // two chunks in flight: exchange + merge on the second stream
     int set = 0;
     size_t n_chunks = 0;
     for (size_t q0 = 0; q0 < nq; q0 += chunk, set ^= 1, ++n_chunks) {
         const size_t nqc = nq - q0 < chunk ? nq - q0 : chunk;
-        const size_t words = packed_words(nqc, kp);
+        const size_t words = packed_words(nqc, kd);
         SPN(d.gathered[set].ensure((size_t)sh->world * words * 8));
         // the packed buffer of this set is free again once the exchange that read it (two chunks ago) has been merged
         if (overlapped && n_chunks >= 2) SHIP(hipStreamWaitEvent(s, d.ev_merged[set], 0));
-        SPN(enqueue_local(sh, d, d_q + q0 * q_stride, nqc, q_cols, q_stride, k, kp, set, s));
+        SPN(enqueue_local(sh, d, d_q + q0 * q_stride, nqc, q_cols, q_stride, k, kp, kd, set, s));
         hipStream_t xs = s;
         if (overlapped) {
             SHIP(hipEventRecord(d.ev_local[set], s));
@@ -472,7 +492,7 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
             xs = d.comm_stream;
         }
         SNCCL(rccl().AllGather(d.pack[set].p, d.gathered[set].p, words, ncclUint64, d.comm, xs));
-        SPN(enqueue_merge(sh, d, nqc, kp, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
+        SPN(enqueue_merge(sh, d, nqc, kd, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
         if (overlapped) SHIP(hipEventRecord(d.ev_merged[set], xs));
     }
     if (overlapped) {  // results are ready in the order of the caller's stream
@@ -502,7 +522,7 @@ extern "C" int pn_sharded_query_device_f32(const pn_sharded *sh, const float *d_
 extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
                                     ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out) {
     if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
-    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k);
+    const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k), kd = k_dev_of(sh, k);
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
     if (!idx_out || !dist_out) return set_error(PN_ERR_INVALID, "output buffer is NULL");
@@ -534,11 +554,11 @@ extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, 
                              (float *)d0.out_dist.p, d0.stream));
     } else {
         // one process, several GPUs: local work on every GPU, ONE grouped all-gather, merge on the first GPU
-        const size_t words = packed_words(nq, kp);
+        const size_t words = packed_words(nq, kd);
         for (Dev &d : devs) {
             SetGuard g(d.device);
             SPN(d.gathered[0].ensure((size_t)sh->world * words * 8));
-            SPN(enqueue_local(sh, d, (const float *)d.q.p, nq, q_cols, qc, k, kp, 0, d.stream));
+            SPN(enqueue_local(sh, d, (const float *)d.q.p, nq, q_cols, qc, k, kp, kd, 0, d.stream));
         }
         SNCCL(rccl().GroupStart());
         for (Dev &d : devs) {
@@ -550,7 +570,7 @@ extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, 
         }
         SNCCL(rccl().GroupEnd());
         SetGuard g(d0.device);
-        SPN(enqueue_merge(sh, d0, nq, kp, k_out, 0, (uint64_t *)d0.out_idx.p, (float *)d0.out_dist.p, d0.stream));
+        SPN(enqueue_merge(sh, d0, nq, kd, k_out, 0, (uint64_t *)d0.out_idx.p, (float *)d0.out_dist.p, d0.stream));
     }
     {
         SetGuard g(d0.device);

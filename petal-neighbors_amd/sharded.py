@@ -1,16 +1,19 @@
 """Row-sharded exact k-NN over the GPUs of one node.
 
-One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on
-ROCm, ``gloo`` in the CPU tests).  The corpus is split by contiguous row ranges;
-every rank sees all queries, answers them on its shard with global indices
-(``PN_OPT_INDEX_BASE``), and ONE all-gather of the per-shard ``(idx, dist)``
-top-k per batch feeds a local merge ordered by (distance, index).  Exact top-k
-is decomposable -- top-k of a union is top-k of the per-part top-k's -- and the
-(distance, index) order is total, so results are identical at any world size.
+The exchange lives BEHIND the C ABI (``pn_sharded_*``, csrc/sharded.hip): row shards with global indices
+(``PN_OPT_INDEX_BASE``), ONE ``ncclAllGather`` (RCCL over xGMI) of the packed per-GPU ``{idx | dist}`` top-k per
+query batch, a HIP merge kernel ordered by (distance, index).  Exact top-k is decomposable -- top-k of a union is
+top-k of the per-part top-k's -- and the order is total, so results are identical for any number of shards.
 
-The per-rank engine is pluggable so the host logic (bounds, padding, gather,
-merge call pattern) is testable on CPU with ``gloo``; the default engine is the
-HIP path and there is no CPU engine in this package.
+* ``ShardedIndex``     -- ctypes view of a ``pn_sharded`` handle: one process over several GPUs
+                          (``from_host(points, devices)``) or one process per GPU (``from_rank_device``).
+* ``ShardedBallTree``  -- ``BallTree``-shaped front for one-process-per-GPU programs (``torch.distributed`` carries
+                          the 128-byte communicator id to the ranks, nothing else); its per-rank engine is
+                          pluggable so the host logic is testable on CPU with ``gloo`` and an oracle-backed engine
+                          (tests/test_sharded_gloo.py).  ``AbiShardEngine`` (default) hands the whole batch to
+                          ``pn_sharded_query_device_f32``; ``HipShardEngine`` keeps the exchange in
+                          ``torch.distributed`` (one ``all_gather_into_tensor``) for comparison.
+There is no CPU engine in this package.
 """
 from __future__ import annotations
 
@@ -22,15 +25,201 @@ ABSENT = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def shard_bounds(n: int, world: int, rank: int):
-    """Contiguous row range [lo, hi) of ``rank``: ceil(n / world) rows per shard."""
+    """Contiguous row range [lo, hi) of ``rank``: ceil(n / world) rows per shard; the same
+    rule as csrc/sharded.hip."""
     per = (n + world - 1) // world
     lo = min(n, rank * per)
     hi = min(n, lo + per)
     return lo, hi
 
 
+class ShardedIndex:
+    """A ``pn_sharded`` handle (include/petal_mi355x.h): row shards + RCCL exchange behind the ABI."""
+
+    def __init__(self, handle, keep=None):
+        from . import _lib
+        from .errors import check
+        self._h = C.c_void_p(handle)
+        self._keep = keep
+        info = _lib.PnShardedInfo()
+        check(_lib.lib().pn_sharded_info(self._h, C.byref(info)))
+        self.n, self.dim = int(info.n_points), int(info.dim)
+        self.n_shards, self.world, self.rank = int(info.n_shards), int(info.world), int(info.rank)
+        self.local_first_row, self.local_rows = int(info.local_first_row), int(info.local_rows)
+        self.mfma_eligible, self.bf16_eligible = bool(info.mfma_eligible), bool(info.bf16_eligible)
+
+    @classmethod
+    def from_host(cls, points, devices):
+        """``BallTree::new`` over ``len(devices)`` row shards driven by this process; shard g lives on
+        ``devices[g]`` (a device may be named several times)."""
+        from . import _lib
+        from .errors import check
+        a = np.asarray(points)
+        if a.dtype != np.float32:
+            a = a.astype(np.float32)
+        if a.ndim != 2:
+            raise ValueError("points must be a 2-D array (Ix2)")
+        n, d = a.shape
+        item = a.itemsize
+        rs, cs = (a.strides[0] // item, a.strides[1] // item) if n and d else (max(d, 1), 1)
+        devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = C.c_void_p(0)
+        check(_lib.lib().pn_sharded_create_f32(a.ctypes.data if a.size else None, n, d, rs, cs if d > 1 else 1, devs,
+                                               len(devices), C.byref(h)))
+        return cls(h.value, keep=a)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        from .errors import check
+        buf = C.create_string_buffer(_lib.PN_COMM_ID_BYTES)
+        check(_lib.lib().pn_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_rank_device(cls, rows, n_total: int, rank: int, world: int, comm_id: bytes, device: int, stream=None):
+        """One process per GPU: ``rows`` = this rank's shard (float32 CUDA tensor, or None for an empty shard)."""
+        import torch
+        from . import _lib
+        from .errors import check
+        h = C.c_void_p(0)
+        if rows is not None and rows.numel():
+            if rows.dtype != torch.float32 or rows.dim() != 2 or not rows.is_cuda or (rows.shape[1] > 1 and rows.stride(1) != 1):
+                raise ValueError("rows must be a row-major 2-D float32 CUDA tensor")
+            ptr, nl, d, ld = rows.data_ptr(), rows.shape[0], rows.shape[1], (rows.stride(0) if rows.shape[0] > 1 else max(rows.shape[1], 1))
+            st = stream if stream is not None else torch.cuda.current_stream(rows.device).cuda_stream
+        else:
+            ptr, nl, d, ld, st = None, 0, (rows.shape[1] if rows is not None else 0), 1, 0
+        idb = C.create_string_buffer(bytes(comm_id), _lib.PN_COMM_ID_BYTES)
+        check(_lib.lib().pn_sharded_create_rank_device_f32(ptr, nl, d, ld, int(n_total), int(rank), int(world), idb,
+                                                           int(device), C.c_void_p(st), C.byref(h)))
+        return cls(h.value)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            from . import _lib
+            _lib.lib().pn_sharded_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt: int, value: int):
+        from . import _lib
+        from .errors import check
+        check(_lib.lib().pn_sharded_set_option(self._h, opt, int(value)))
+        return self
+
+    def set_engine(self, name: str):
+        from . import _lib
+        from .ball_tree import ENGINES
+        return self.set_option(_lib.PN_OPT_ENGINE, ENGINES[name])
+
+    def stats(self, reset: bool = False):
+        from . import _lib
+        from .errors import check
+        s = _lib.PnStats()
+        check(_lib.lib().pn_sharded_get_stats(self._h, C.byref(s), int(reset)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+    def num_points(self) -> int:
+        return self.n
+
+    def query_batch(self, queries, k: int):
+        """host queries (nq, d) -> (idx uint64, dist float32) of shape (nq, min(k, n))"""
+        from . import _lib
+        from .errors import check
+        a = np.ascontiguousarray(queries, dtype=np.float32)
+        if a.ndim != 2:
+            raise ValueError("queries must be 2-D")
+        nq, qc = a.shape
+        kout = min(int(k), self.n)
+        idx = np.empty((nq, kout), dtype=np.uint64)
+        dist = np.empty((nq, kout), dtype=np.float32)
+        if nq and kout:
+            check(_lib.lib().pn_sharded_query_f32(self._h, a.ctypes.data, nq, qc, max(qc, 1), int(k), idx.ctypes.data,
+                                                  dist.ctypes.data))
+        return idx, dist
+
+    def query(self, point, k: int):
+        i, d = self.query_batch(np.asarray(point, dtype=np.float32).reshape(1, -1), k)
+        return i[0], d[0]
+
+    def query_device(self, queries, k: int, out_idx=None, out_dist=None, stream=None):
+        """queries / results in HBM (torch CUDA tensors), enqueued on the current stream"""
+        import torch
+        from . import _lib
+        from .errors import check
+        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a 2-D float32 CUDA tensor")
+        if queries.shape[1] > 1 and queries.stride(1) != 1:
+            queries = queries.contiguous()
+        nq, qc = queries.shape
+        kout = min(int(k), self.n)
+        if out_idx is None:
+            out_idx = torch.empty((nq, kout), dtype=torch.int64, device=queries.device)
+        if out_dist is None:
+            out_dist = torch.empty((nq, kout), dtype=torch.float32, device=queries.device)
+        if nq and kout:
+            st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
+            check(_lib.lib().pn_sharded_query_device_f32(self._h, queries.data_ptr(), nq, qc,
+                                                         queries.stride(0) if nq > 1 else max(qc, 1), int(k),
+                                                         out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
+        return out_idx, out_dist
+
+    def query_radius_batch(self, queries, distance):
+        """CSR (offsets[nq+1], indices) of ``{ i : dist(q, p_i) < distance }`` over all shards, ascending per query."""
+        from . import _lib
+        from .errors import check
+        a = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, qc = a.shape
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        out = C.c_void_p(0)
+        check(_lib.lib().pn_sharded_query_radius_f32(self._h, a.ctypes.data, nq, qc, max(qc, 1), C.c_float(distance),
+                                                     offsets.ctypes.data, C.byref(out)))
+        total = int(offsets[-1])
+        try:
+            idx = (np.frombuffer((C.c_uint64 * total).from_address(out.value), dtype=np.uint64).copy()
+                   if total else np.empty(0, dtype=np.uint64))
+        finally:
+            if out.value:
+                _lib.lib().pn_free(out)
+        return offsets, idx
+
+
+class AbiShardEngine:
+    """Default engine of ``ShardedBallTree``: the whole batch -- local shard, all-gather, merge -- is ONE call into
+    the C ABI (``pn_sharded_query_device_f32``); ``torch.distributed`` only carried the communicator id."""
+    collective = True
+
+    def __init__(self, device: int):
+        self.device = device
+        self.index = None
+
+    def build_rank(self, rows, n_total, rank, world, comm_id):
+        self.index = ShardedIndex.from_rank_device(rows, n_total, rank, world, comm_id, self.device)
+
+    @property
+    def tree(self):  # option / statistics target (bench.py)
+        return self.index
+
+    def query_all(self, queries, k: int):
+        return self.index.query_device(queries, k)
+
+    def radius_all(self, queries, r: float):
+        q = queries.cpu().numpy() if hasattr(queries, "cpu") else np.asarray(queries)
+        return self.index.query_radius_batch(q, r)
+
+    def empty(self, shape, dtype):
+        import torch
+        return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+
 class HipShardEngine:
-    """Default engine: local ``BallTree`` on the rank's GPU + the HIP merge kernel."""
+    """Local ``BallTree`` on the rank's GPU + the HIP merge kernel; the exchange stays in ``torch.distributed``."""
 
     def __init__(self, device: int):
         self.device = device
@@ -128,10 +317,25 @@ class ShardedBallTree:
         self.lo, self.hi = shard_bounds(self.n, self.world, self.rank)
         if engine is None:
             import torch
-            engine = HipShardEngine(torch.cuda.current_device())
+            engine = AbiShardEngine(torch.cuda.current_device())
         self.engine = engine
         self.n_local = self.hi - self.lo
-        if self.n_local > 0:
+        if getattr(engine, "collective", False):
+            # the ABI owns the exchange: all it needs from this program is the communicator id on every rank
+            import torch
+            rows = points_fn(self.lo, self.hi) if self.n_local > 0 else None
+            if rows is not None and not isinstance(rows, torch.Tensor):
+                rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(f"cuda:{engine.device}")
+            cid = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                cid = torch.frombuffer(bytearray(ShardedIndex.unique_id()), dtype=torch.uint8).clone()
+            if self.world > 1:
+                on_gpu = dist.get_backend(group) == "nccl"
+                t = cid.to(f"cuda:{engine.device}") if on_gpu else cid
+                dist.broadcast(t, src=0, group=group)
+                cid = t.cpu()
+            engine.build_rank(rows, self.n, self.rank, self.world, bytes(cid.numpy().tobytes()))
+        elif self.n_local > 0:
             self.engine.build(points_fn(self.lo, self.hi), self.lo)
 
     def num_points(self) -> int:
@@ -144,6 +348,8 @@ class ShardedBallTree:
         k_out = min(int(k), self.n)
         if k_out == 0 or nq == 0:
             return (self.engine.empty((nq, 0), torch.int64), self.engine.empty((nq, 0), torch.float32))
+        if getattr(self.engine, "collective", False):
+            return self.engine.query_all(queries, k_out)
         if self.world == 1:
             return self.engine.query(queries, k_out)
         k_part = min(int(k), max(shard_bounds(self.n, self.world, 0)[1], 1))  # largest shard
@@ -175,6 +381,8 @@ class ShardedBallTree:
         concatenating per-shard ascending lists in rank order is globally ascending."""
         import torch
         nq = queries.shape[0]
+        if getattr(self.engine, "collective", False):
+            return self.engine.radius_all(queries, r)
         if self.n_local > 0:
             off, ids = self.engine.radius(queries, r)
         else:

@@ -62,6 +62,22 @@ def corpus_columns(p, mu=None):
     return ph64, np.stack([h0, h1, h2], 1).astype(np.float64), bp.astype(np.float64), dp.astype(np.float64)
 
 
+def corpus_norm_f32(p, mu=None):
+    """layout 2: |p - mu|^2 (1 - g), rounded down to f32 -- the accumulator's initial value"""
+    p64 = p.astype(np.float64) - (0.0 if mu is None else mu.astype(np.float64)[None, :])
+    return f_down((p64 * p64).sum(1) * (1.0 - G) / UP).astype(np.float64)
+
+
+def row_constants_f64(p, mu=None):
+    """Bp, Dp before their bf16 rounding (bf16_row_stats_kernel): layout 2 uses their maxima over the corpus"""
+    p64 = p.astype(np.float64) - (0.0 if mu is None else mu.astype(np.float64)[None, :])
+    ph64 = bf16_rne(p64.astype(np.float32)).astype(np.float64)
+    pn, en, hn = (p64 * p64).sum(1), ((p64 - ph64) ** 2).sum(1), (ph64 * ph64).sum(1)
+    bp = (2.0 * np.sqrt(en) * UP + 2.0 * G * np.sqrt(hn) * UP) * (1.0 + 2.0 * G) * UP
+    dp = 2.0 * np.sqrt(pn) * UP * (1.0 + 2.0 * G) * UP
+    return bp, dp
+
+
 def query_columns(q, mu=None):
     q64 = q.astype(np.float64) - (0.0 if mu is None else mu.astype(np.float64)[None, :])
     qh = bf16_rne(q64.astype(np.float32))
@@ -114,3 +130,27 @@ def test_bound_is_tight_enough_to_be_useful_on_uniform_data():
     d2 = ((q.astype(np.float64)[:, None, :] - p.astype(np.float64)[None, :, :]) ** 2).sum(2)
     gap = d2 - (exact + qn[:, None])
     assert gap.min() > 0 and gap.max() < 0.2          # squared distances are ~21 +- 2.2 here
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("dim", [32, 96, 128])
+def test_norm_in_accumulator_layout_bound_holds(name, dim):
+    """Layout 2 (bf16_filter.hip, bf16_ci_dim): value = norm_f32 + sum (-2 q^_k) p^_k, and the proof adds back
+    |q|^2_down - E(q) with E(q) = |q^|_up Bmax + |eq|_up Dmax.  With the accumulation allowance g (|norm| + sum |products|):
+        exact + g * mags - E(q)  <=  |q - p|^2 - |q|^2_down."""
+    p = CASES[name](400, dim, 13)
+    q = CASES[name](60, dim, 14)
+    mu = p.astype(np.float64).mean(0).astype(np.float32)
+    ph, _, _, _ = corpus_columns(p, mu)
+    cn = corpus_norm_f32(p, mu)
+    bp, dp = row_constants_f64(p, mu)
+    mq, _, _, qn = query_columns(q, mu)
+    q64 = q.astype(np.float64) - mu.astype(np.float64)[None, :]
+    qh64 = bf16_rne(q64.astype(np.float32)).astype(np.float64)
+    eq = (np.sqrt((qh64 * qh64).sum(1)) * UP * bp.max() + np.sqrt(((q64 - qh64) ** 2).sum(1)) * UP * dp.max()) * UP
+    exact = cn[None, :] + mq @ ph.T
+    mags = cn[None, :] + np.abs(mq) @ np.abs(ph).T
+    p64 = p.astype(np.float64)
+    d2 = ((q.astype(np.float64)[:, None, :] - p64[None, :, :]) ** 2).sum(2)
+    slack = (d2 - (qn - eq)[:, None]) - (exact + G * mags)
+    assert (slack >= -1e-12 * (mags + eq[:, None])).all(), f"{name}/D={dim}: margin violated by {slack.min()}"

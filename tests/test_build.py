@@ -64,3 +64,58 @@ def test_exact_kernels_do_not_spill(asm):
     for unit, text in asm.items():
         for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", text):
             assert int(m.group(1)) == 0, unit
+
+
+def test_product_library_carries_no_diagnostic_flags():
+    """timing-only PN_DIAG_* builds give wrong results; the flag set is stamped next to the objects and a
+    plain build() rebuilds when it differs -- the library the tests and bench.py load is the product build."""
+    import importlib.util as u
+    spec = u.spec_from_file_location("pn_build", os.path.join(ROOT, "petal-neighbors_amd", "build.py"))
+    b = u.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if os.environ.get("PN_DIAG_FLAGS"):
+        pytest.skip("a diagnostic build was asked for explicitly")
+    b.build()
+    assert b.build_flags() == ""
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The oracle's C restatement under -fsanitize=address,undefined (oracle/Makefile `asan`), in a child process
+    (the sanitizer runtime must be the first library loaded): golden vector G1, the faithful tree against the
+    brute force, radius, pairwise and the degenerate 8-identical-points build."""
+    import subprocess
+    import sys
+    mk = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"], capture_output=True, text=True)
+    assert mk.returncode == 0, mk.stderr
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not found")
+    script = tmp_path / "asan_child.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+import oracle
+oracle._LIB_PATH = {os.path.join(ROOT, 'oracle', 'liboracle_asan.so')!r}
+pts = np.array([[1., 1.], [1., 2.], [9., 9.]])
+t = oracle.Tree(pts)
+i, d = t.query(np.array([3., 3.]), 2)
+assert list(i) == [1, 0] and abs(d[0] - 5 ** 0.5) < 1e-15
+rng = np.random.default_rng(3)
+for dt in (np.float32, np.float64):
+    p = rng.random((300, 5)).astype(dt); q = rng.random((20, 5)).astype(dt)
+    t = oracle.Tree(p)
+    ti, td = t.query_batch(q, 7, nthreads=2)
+    bi, bd = oracle.brute_knn(p, q, 7)
+    assert td.tobytes() == bd.tobytes()
+    for a in range(20):
+        assert sorted(t.query_radius(q[a], dt(0.4)).tolist()) == oracle.brute_radius(p, q[a], dt(0.4)).tolist()
+        t.query_nearest(q[a])
+    oracle.pairwise(p[:40]); oracle.pairwise_cosine(p[:40])
+same = oracle.Tree(np.ones((8, 2)))
+assert same.query(np.array([1., 2.]), 3)[1].tolist() == [1.0, 1.0, 1.0]
+print("ASAN_OK")
+""")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ASAN_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -52,7 +52,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("dim", [8, 33, 96, 128])
+@pytest.mark.parametrize("dim", [8, 33, 96, 110, 128])
 def test_lower_bound_inequality(pn, name, dim):
     n, nq = 4096, 96
     pts = CASES[name](n, dim, 11)
@@ -62,7 +62,12 @@ def test_lower_bound_inequality(pn, name, dim):
     L, qn, mu = _bounds(pn, tree, qs, 1024)
     p64, q64 = pts[:1024].astype(np.float64), qs.astype(np.float64)
     qq = ((q64 - mu.astype(np.float64)) ** 2).sum(1)  # the tier works with vectors translated by the corpus mean
-    assert np.all(qn <= qq) and np.all(qn >= qq * (1 - 1e-11))
+    assert np.all(qn <= qq)
+    if tree.bf16_layout == 1:
+        assert np.all(qn >= qq * (1 - 1e-11))
+    else:  # layout 2: the per-query error constant E(q) is already subtracted (bf16_filter.hip, bf16_ci_dim)
+        assert tree.bf16_layout == 2 and dim % 16 in (0, 12, 13, 14, 15) and dim >= 17
+        assert np.all(qn >= qq - 0.05 * qq - 1e-30)
     # the translation is the corpus mean where that shrinks the squared norms at least 16x, else none
     assert np.all(mu == 0) or np.allclose(mu, pts.astype(np.float64).mean(0), rtol=1e-5, atol=1e-30)
     if name == "offset1000":
@@ -91,8 +96,15 @@ def test_matrix_core_accumulation_error_is_far_inside_the_allowance(pn, name, di
     L, _, mu = _bounds(pn, tree, qs, n)
     ph, pieces, bp, dp = corpus_columns(pts, mu)
     mq, aq, cq, _ = query_columns(qs, mu)
-    exact = pieces.sum(1)[None, :] + mq @ ph.T - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
-    mags = pieces.sum(1)[None, :] + np.abs(mq) @ np.abs(ph).T + aq[:, None] * bp[None, :] + cq[:, None] * dp[None, :]
+    if tree.bf16_layout == 2:
+        # the chain is the row norm (one f32, the accumulator's initial value) + the data products, nothing else
+        from test_bf16_bound_model import corpus_norm_f32
+        cn = corpus_norm_f32(pts, mu)
+        exact = cn[None, :] + mq @ ph.T
+        mags = cn[None, :] + np.abs(mq) @ np.abs(ph).T
+    else:
+        exact = pieces.sum(1)[None, :] + mq @ ph.T - aq[:, None] * bp[None, :] - cq[:, None] * dp[None, :]
+        mags = pieces.sum(1)[None, :] + np.abs(mq) @ np.abs(ph).T + aq[:, None] * bp[None, :] + cq[:, None] * dp[None, :]
     ratio = np.abs(L.astype(np.float64) - exact) / (G * mags)
     print(f"{name}/D={dim}: accumulation error / allowance: max {ratio.max():.4f}, mean {ratio.mean():.5f}")
     assert ratio.max() < 0.1, f"matrix-core accumulation error uses {ratio.max():.3f} of the allowance"
@@ -250,3 +262,19 @@ def test_bf16_radius_boundary_on_tight_bounds(pn, oracle_mod):
                     for a in np.nonzero(rs == r)[0][:4]:
                         want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
                         assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), (n, dim, j, bump, float(r), int(a))
+
+
+def test_heterogeneous_norms_keep_the_per_row_layout(pn, oracle_mod):
+    """The norm-in-the-accumulator layout replaces each row's error constants by the corpus maxima: rows of very
+    different norms would make that bound useless, so such a corpus keeps the five per-row columns (layout 1) --
+    and answers stay exact either way."""
+    rng = np.random.default_rng(9)
+    pts = uniform((20000, 128), 31) * (10.0 ** rng.integers(-2, 3, size=(20000, 1))).astype(np.float32)
+    qs = pts[rng.integers(0, 20000, size=200)] + uniform((200, 128), 32) * np.float32(0.01)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible and tree.bf16_layout == 1
+    assert pn.BallTree.euclidean(uniform((20000, 128), 33)).bf16_layout == 2
+    tree.set_engine("bf16")
+    idx, dist = tree.query_batch(qs, 10)
+    oi, od = oracle_mod.brute_knn(pts, qs, 10)
+    assert dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)

@@ -1,6 +1,7 @@
 """Event counts of the bf16 filter (needs a PN_DIAG_FLAGS=-DPN_DIAG_BF_COUNT build).  usage: count_events_bf.py [slots] [k]"""
 import sys, ctypes as C, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import petal_neighbors_amd as pn
 from petal_neighbors_amd import _lib
 L = _lib.lib()
@@ -17,9 +18,13 @@ f = L.pn_debug_read_bf; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int]
 out = (C.c_ulonglong * 8)()
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
-units = 40 * 4 * 2 * 31250
-print("slow calls", out[0], "(%.3f of wave-block-qb units)" % (out[0] / units), "appends", out[1], "per query %.1f" % (out[1] / 10240),
-      "lanes with survivors per call %.2f" % (out[4] / max(out[0], 1)), "compactions", out[2],
-      "per slow call: %.0f ns = count %.0f + append %.0f + compaction check %.0f;" % tuple(10 * out[i] / max(out[0], 1) for i in (3, 5, 6, 7)),
-      "per compaction %.2f us; per wave: slow path %.2f ms of which compactions %.2f ms" % (10e-3 * out[7] / max(out[2], 1), 10e-6 * out[3] / 2048, 10e-6 * out[7] / 2048),
-      "")
+waves = 480 * 4
+ns = lambda i: 10.0 * out[i]   # s_memtime ticks of 10 ns
+print("main launch only (the scout-only launch touches no buffers); per wave, of %d waves:" % waves)
+print("  run time            %8.3f ms" % (ns(7) / waves * 1e-6))
+print("  rare path (bf_slow) %8.3f ms in %.0f entries (%.0f ns each), %.1f appends per (segment, query) buffer" %
+      (ns(3) / waves * 1e-6, out[0] / waves, ns(3) / max(out[0], 1), out[1] / (480 * 256)))
+print("  ... of which mid-run compactions %8.3f ms in %.1f compactions (%.2f us each)" %
+      (ns(4) / waves * 1e-6, out[2] / waves, ns(4) / max(out[2], 1) * 1e-3))
+print("  end of run (final compactions + publish) %8.3f ms" % (ns(5) / waves * 1e-6))
+print("  tile barrier incl. DMA wait %8.3f ms" % (ns(6) / waves * 1e-6))
