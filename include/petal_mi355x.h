@@ -134,6 +134,16 @@ int pn_index_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdi
                         ptrdiff_t col_stride, int device, pn_index **out);
 int pn_index_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
                         ptrdiff_t col_stride, int device, pn_index **out);
+/* BallTree::new(points, Cosine) (src/ball_tree.rs:38 with src/distance.rs:76-122).  Cosine distance is not a metric
+ * (no triangle inequality), so the reference's ball-pruned walk may skip true neighbours under it and its answers
+ * depend on the tree's shape; this engine does not walk a tree: every query function on a Cosine index is an EXACT scan
+ * -- the k smallest (Cosine::distance, index) / every row with Cosine::distance < r -- in the reference's arithmetic
+ * (three sequential sums, 1 - dot / (|a| |b|), zip-truncated dot product).  Where the reference's walk prunes nothing
+ * the two agree bit for bit; where it prunes wrongly this engine returns the true nearest rows.  Exact scan engine only. */
+int pn_index_create_cosine_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                               ptrdiff_t col_stride, int device, pn_index **out);
+int pn_index_create_cosine_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                               ptrdiff_t col_stride, int device, pn_index **out);
 /* same, from rows already resident on `device` (row-major, inner stride 1) */
 int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
                                int device, void *stream, pn_index **out);
@@ -183,6 +193,12 @@ int pn_pairwise_f32(const float *x, size_t n_rows, size_t n_cols, ptrdiff_t row_
                     float *out);
 int pn_pairwise_f64(const double *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,
                     double *out);
+/* the same with rows and the n x n result in HBM (extension; row_stride >= n_cols elements), enqueued on `stream` and
+ * complete when the call returns.  Only the pairs i < j are evaluated, each written twice (src/distance.rs:66-72). */
+int pn_pairwise_device_f32(const float *d_x, size_t n_rows, size_t n_cols, size_t row_stride, int device, float *d_out,
+                           void *stream);
+int pn_pairwise_device_f64(const double *d_x, size_t n_rows, size_t n_cols, size_t row_stride, int device,
+                           double *d_out, void *stream);
 
 /* ---- Metric<A> for Euclidean (src/distance.rs:21-55): scalar, host-side by
  * design (one pair per call is not GPU work); bit-exact with the batched path. */
@@ -198,8 +214,7 @@ double pn_distance_to_rdistance_f64(double d);
 /* ---- Metric<A> for Cosine (src/distance.rs:76-122): distance = 1 - dot / (|a| |b|) with the reference's three
  * sequential sums (the dot product over the shorter length, each norm over its own vector); rdistance and both
  * conversions are the identity there.  pn_pairwise_cosine_*: distance::pairwise(x, &Cosine) on the GPU, same
- * contract as pn_pairwise_*.  BallTree::new(points, Cosine) is NOT offered: cosine distance is not a metric, the
- * reference's pruned walk returns walk-dependent answers under it, and this engine replaces that walk. */
+ * contract as pn_pairwise_*.  BallTree::new(points, Cosine): pn_index_create_cosine_* above. */
 float pn_cosine_f32(const float *a, size_t len_a, const float *b, size_t len_b);
 double pn_cosine_f64(const double *a, size_t len_a, const double *b, size_t len_b);
 int pn_pairwise_cosine_f32(const float *x, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, int device,

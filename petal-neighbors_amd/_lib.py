@@ -52,6 +52,10 @@ SIGNATURES = {
     "pn_device_count": (_i, [C.POINTER(_i)]),
     "pn_index_create_f32": (_i, [_vp, _sz, _sz, _ssz, _ssz, _i, C.POINTER(_vp)]),
     "pn_index_create_f64": (_i, [_vp, _sz, _sz, _ssz, _ssz, _i, C.POINTER(_vp)]),
+    "pn_index_create_cosine_f32": (_i, [_vp, _sz, _sz, _ssz, _ssz, _i, C.POINTER(_vp)]),
+    "pn_index_create_cosine_f64": (_i, [_vp, _sz, _sz, _ssz, _ssz, _i, C.POINTER(_vp)]),
+    "pn_pairwise_device_f32": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp]),
+    "pn_pairwise_device_f64": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp]),
     "pn_index_create_device_f32": (_i, [_vp, _sz, _sz, _sz, _i, _vp, C.POINTER(_vp)]),
     "pn_index_destroy": (None, [_vp]),
     "pn_index_info": (_i, [_vp, C.POINTER(PnInfo)]),

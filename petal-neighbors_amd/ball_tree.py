@@ -55,10 +55,10 @@ class BallTree:
 
         Raises ``ArrayError.Empty`` for zero rows and ``ArrayError.NotContiguous`` when the
         inner stride is not 1 (only the inner stride is checked, as at :47)."""
-        if not isinstance(metric, Euclidean):
-            raise NotImplementedError("only distance.Euclidean is on the MI355X path (distance.Cosine is served as a "
-                                      "pair metric and by distance.pairwise: it is not a metric, so the reference's "
-                                      "pruned walk under it has no walk-independent answer to reproduce)")
+        from .distance import Cosine
+        if not isinstance(metric, (Euclidean, Cosine)):
+            raise NotImplementedError("the MI355X path serves distance.Euclidean and distance.Cosine")
+        cosine = isinstance(metric, Cosine)
         a = _float_array(points)
         if a.ndim != 2:
             raise ValueError("points must be a 2-D array (Ix2)")
@@ -75,7 +75,10 @@ class BallTree:
                 rs = d
         L = _lib.lib()
         h = C.c_void_p(0)
-        fn = L.pn_index_create_f32 if a.dtype == np.float32 else L.pn_index_create_f64
+        # Cosine: an exact scan under Cosine::distance (it is not a metric: the reference's pruned walk can miss true
+        # neighbours under it; include/petal_mi355x.h, pn_index_create_cosine_*)
+        sfx = "f32" if a.dtype == np.float32 else "f64"
+        fn = getattr(L, f"pn_index_create_cosine_{sfx}" if cosine else f"pn_index_create_{sfx}")
         check(fn(a.ctypes.data if a.size else None, n, d, rs, cs, device, C.byref(h)))
         return cls(h.value, a, metric, a.dtype, device)
 

@@ -24,8 +24,11 @@ ARCH = "gfx950"
 # flags give wrong results by design, and nothing a diagnostic build does may touch the product library.  Load one with
 # PN_LIBRARY_PATH=<path> (petal-neighbors_amd/_lib.py).
 DIAG = os.environ.get("PN_DIAG_FLAGS", "").split()
-BUILD = os.path.join(HERE, "build_diag" if DIAG else "build")
-LIB = os.path.join(HERE, "libpetal_mi355x_diag.so" if DIAG else "libpetal_mi355x.so")
+_TAG = os.environ.get("PN_DIAG_TAG", "")  # several diagnostic variants side by side: ..._diag_<tag>.so
+_SFX = ("_diag" + ("_" + _TAG if _TAG else "")) if DIAG else ""
+BUILD_PRODUCT = os.path.join(HERE, "build")
+BUILD = os.path.join(HERE, "build" + _SFX)
+LIB = os.path.join(HERE, "libpetal_mi355x" + _SFX + ".so")
 
 # (source, extra flags)
 UNITS = [
@@ -78,6 +81,12 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
+        if DIAG and "PN_DIAG" not in open(sp).read():
+            # a unit that never looks at a diagnostic flag: the product object is the same object
+            prod = os.path.join(BUILD_PRODUCT, os.path.splitext(src)[0] + ".o")
+            if os.path.exists(prod) and not _stale(prod, [sp, me] + HEADERS):
+                objs.append(prod)
+                continue
         objs.append(obj)
         if force or _stale(obj, [sp, me] + HEADERS):
             lang = ["-x", "hip"] if src.endswith(".hip") else []

@@ -45,6 +45,19 @@ __device__ __forceinline__ uint32_t dist_key(float d) {
 __device__ __forceinline__ uint64_t dist_key(double d) {
     return (d != d) ? KeyOf<double>::kNaN : (uint64_t)__double_as_longlong(d);
 }
+// Cosine distances can be negative (1 - dot / (|a||b|) a few ulp below zero): their keys use the order-preserving map
+// of all floats (sign bit flipped for x >= +0, all bits for x < 0; -0 counts as +0, NaN above +inf as in ordered-float);
+// select.hip maps them back (signed_keys)
+__device__ __forceinline__ uint32_t dist_key_signed(float d) {
+    if (d != d) return 0xFFC00000u;
+    const uint32_t b = __float_as_uint(d == 0.0f ? 0.0f : d);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t dist_key_signed(double d) {
+    if (d != d) return 0xFFF8000000000000ull;
+    const uint64_t b = (uint64_t)__double_as_longlong(d == 0.0 ? 0.0 : d);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
 __device__ __forceinline__ float pn_sqrt(float x) { return sqrtf(x); }   // correctly rounded (default hipcc)
 __device__ __forceinline__ double pn_sqrt(double x) { return sqrt(x); }
 
@@ -78,7 +91,9 @@ __device__ __forceinline__ void stage_chunk(const T *__restrict__ src, size_t ld
     }
 }
 
-template <typename T>
+// COS: acc[qi][pi] = fold over k of q * p instead (the dot product of Cosine::distance, src/distance.rs:86-90:
+// multiply and add separately rounded, ascending k).
+template <typename T, bool COS = false>
 __device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ldp, const T *__restrict__ Qt,
                                              size_t ldq, int dim, bool stage_q, T (&acc)[4][4],
                                              T (*Qs)[kTileQ], T (*Ps)[kTileP], int tid, int qb, int pb) {
@@ -104,9 +119,14 @@ __device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ld
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const T diff = q[a] - p[b];   // v1 - v2 with v1 = query (src/ball_tree.rs:218)
-                    const T sq = diff * diff;
-                    acc[a][b] = acc[a][b] + sq;
+                    if (COS) {
+                        const T pr = q[a] * p[b];
+                        acc[a][b] = acc[a][b] + pr;
+                    } else {
+                        const T diff = q[a] - p[b];   // v1 - v2 with v1 = query (src/ball_tree.rs:218)
+                        const T sq = diff * diff;
+                        acc[a][b] = acc[a][b] + sq;
+                    }
                 }
         }
     }
@@ -115,13 +135,16 @@ __device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ld
 // ---------------------------------------------------------------------------
 // k-NN scan.  grid = (query tiles, segments), block = 256.
 // ---------------------------------------------------------------------------
-template <typename T, int M>
+// COS: Cosine::distance = 1 - dot / (|q| |p|) (src/distance.rs:85-107) with the row norms pnorm[n_pad] and the query
+// norms qnorm[nq_pad] computed by cosine_norms_kernel (each over its OWN vector's full length; the dot product over
+// the shorter one -- the zip).
+template <typename T, int M, bool COS>
 __global__ __launch_bounds__(256) void exact_knn_kernel(
     const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq,
     uint32_t kp, size_t seg_len, typename KeyOf<T>::type *__restrict__ ckey, uint32_t *__restrict__ cidx,
     uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad,
     const typename KeyOf<T>::type *__restrict__ lo_key, const uint32_t *__restrict__ lo_idx,
-    const uint32_t *__restrict__ nq_dev, uint32_t nq_off) {
+    const uint32_t *__restrict__ nq_dev, uint32_t nq_off, const T *__restrict__ pnorm, const T *__restrict__ qnorm) {
     using KeyT = typename KeyOf<T>::type;
     constexpr uint32_t CAP = 64u * M;
     constexpr KeyT KMAX = KeyOf<T>::kMax;
@@ -165,8 +188,16 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
     bool first = true;
     for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
         T acc[4][4];
-        compute_tile<T>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
         first = false;
+        T qn4[4] = {(T)0, (T)0, (T)0, (T)0}, pn4[4] = {(T)0, (T)0, (T)0, (T)0};
+        if (COS) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                qn4[a] = qnorm[q0 + qb + a];
+                pn4[a] = pnorm[p0 + pb + a];
+            }
+        }
 
         KeyT key[4][4];
         KeyT tau_r[4];
@@ -178,7 +209,8 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const bool v = qv && (p0 + pb + b) < p_end;
-                KeyT kk = v ? dist_key(pn_sqrt(acc[a][b])) : KMAX;
+                KeyT kk = !v ? KMAX
+                               : COS ? dist_key_signed((T)1 - acc[a][b] / (qn4[a] * pn4[b])) : dist_key(pn_sqrt(acc[a][b]));
                 if (bounded && !(kk > lok[a] || (kk == lok[a] && (uint32_t)(p0 + pb + b) > loi[a]))) kk = KMAX;
                 key[a][b] = kk;
                 anyp |= kk < tau_r[a];
@@ -229,15 +261,24 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
 template <typename T>
 static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
                                    int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                   const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                   const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const T *pnorm,
+                                   const T *qnorm, hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
+    const bool cosm = pnorm != nullptr;
     auto *ck = static_cast<KeyT *>(cb.keys);
     auto *ct = static_cast<KeyT *>(cb.tau);
-#define PN_LAUNCH(MM)                                                                                    \
-    hipLaunchKernelGGL((exact_knn_kernel<T, MM>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,          \
+#define PN_LAUNCH1(MM, CC)                                                                               \
+    hipLaunchKernelGGL((exact_knn_kernel<T, MM, CC>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,      \
                        (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad, static_cast<const KeyT *>(lo_key),  \
-                       lo_idx, nq_dev, nq_off)
+                       lo_idx, nq_dev, nq_off, pnorm, qnorm)
+#define PN_LAUNCH(MM)          \
+    do {                       \
+        if (cosm)              \
+            PN_LAUNCH1(MM, true);  \
+        else                   \
+            PN_LAUNCH1(MM, false); \
+    } while (0)
     switch (cb.cap / 64) {
         case 2: PN_LAUNCH(2); break;
         case 4: PN_LAUNCH(4); break;
@@ -246,18 +287,23 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
         default: return hipErrorInvalidValue;
     }
 #undef PN_LAUNCH
+#undef PN_LAUNCH1
     return hipGetLastError();
 }
 
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
-    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const float *pnorm,
+                                const float *qnorm, hipStream_t s) {
+    return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, pnorm,
+                                   qnorm, s);
 }
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
-    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const double *pnorm,
+                                const double *qnorm, hipStream_t s) {
+    return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, pnorm,
+                                    qnorm, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -266,11 +312,11 @@ hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, 
 // into offsets; pass 2 writes indices in row order: within a tile the 16 lanes
 // that share a query scan their per-lane counts with stride-4 shuffles.
 // ---------------------------------------------------------------------------
-template <typename T, bool FILL>
+template <typename T, bool FILL, bool COS>
 __global__ __launch_bounds__(256) void exact_radius_kernel(
     const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq, T r,
     size_t seg_len, int nseg, uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
-    uint64_t *__restrict__ fill, uint64_t index_base) {
+    uint64_t *__restrict__ fill, uint64_t index_base, const T *__restrict__ pnorm, const T *__restrict__ qnorm) {
     __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
     __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
     __shared__ uint32_t cnts[kTileQ];
@@ -295,8 +341,16 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
     bool first = true;
     for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
         T acc[4][4];
-        compute_tile<T>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
         first = false;
+        T qn4[4] = {(T)0, (T)0, (T)0, (T)0}, pn4[4] = {(T)0, (T)0, (T)0, (T)0};
+        if (COS) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                qn4[a] = qnorm[q0 + qb + a];
+                pn4[a] = pnorm[p0 + pb + a];
+            }
+        }
         uint32_t mask[4];
         bool anyp = false;
 #pragma unroll
@@ -306,7 +360,7 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const bool v = qv && (p0 + pb + b) < p_end;
-                const T d = pn_sqrt(acc[a][b]);
+                const T d = COS ? (T)1 - acc[a][b] / (qn4[a] * pn4[b]) : pn_sqrt(acc[a][b]);
                 if (v && d < r) m |= 1u << b;  // NaN distances never match
             }
             mask[a] = m;
@@ -346,43 +400,57 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
 template <typename T>
 static hipError_t launch_exact_radius(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
                                       T r, size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offsets,
-                                      uint64_t *fill, uint64_t index_base, hipStream_t s) {
+                                      uint64_t *fill, uint64_t index_base, const T *pnorm, const T *qnorm,
+                                      hipStream_t s) {
     dim3 grid((unsigned)(round_up((size_t)nq, kTileQ) / kTileQ), (unsigned)nseg), block(256);
-    if (fill)
-        hipLaunchKernelGGL((exact_radius_kernel<T, true>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r, seg_len,
-                           nseg, counts, offsets, fill, index_base);
-    else
-        hipLaunchKernelGGL((exact_radius_kernel<T, false>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r,
-                           seg_len, nseg, counts, offsets, fill, index_base);
+#define PN_RAD(FF, CC)                                                                                          \
+    hipLaunchKernelGGL((exact_radius_kernel<T, FF, CC>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r, seg_len, \
+                       nseg, counts, offsets, fill, index_base, pnorm, qnorm)
+    if (fill) {
+        if (pnorm) PN_RAD(true, true); else PN_RAD(true, false);
+    } else {
+        if (pnorm) PN_RAD(false, true); else PN_RAD(false, false);
+    }
+#undef PN_RAD
     return hipGetLastError();
 }
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
-                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, hipStream_t s) {
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const float *pnorm,
+                                   const float *qnorm, hipStream_t s) {
     return launch_exact_radius<float>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
-                                      index_base, s);
+                                      index_base, pnorm, qnorm, s);
 }
 hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                    size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
-                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, hipStream_t s) {
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const double *pnorm,
+                                   const double *qnorm, hipStream_t s) {
     return launch_exact_radius<double>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
-                                       index_base, s);
+                                       index_base, pnorm, qnorm, s);
 }
 
 // ---------------------------------------------------------------------------
-// distance::pairwise (src/distance.rs:58-74): out[i][j] = distance(x_i, x_j),
-// zero diagonal.  (a-b)^2 == (b-a)^2 exactly, so computing both triangles
-// equals the reference's mirrored fill.  grid = (tiles, tiles).
+// distance::pairwise (src/distance.rs:58-74): out[i][j] = distance(x_i, x_j), zero diagonal.  Like the reference,
+// only the pairs i < j are evaluated and written twice ((a-b)^2 == (b-a)^2 exactly, so either triangle has the
+// same bits): the grid is the upper triangle of 64 x 64 tiles (a tile pair (ti, tj), ti <= tj, from the linear block
+// number), half the arithmetic of the full square.  VALU-bound: 3 packed vector operations per coordinate of a pair.
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void exact_pairwise_kernel(const T *__restrict__ X, size_t n, int dim, size_t ld,
-                                                             T *__restrict__ out) {
+                                                             T *__restrict__ out, uint32_t tiles) {
     __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
     __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tq = lane & 3, tp = lane >> 2;
     const int qb = wave * 16 + tq * 4, pb = tp * 4;
-    const size_t q0 = (size_t)blockIdx.x * kTileQ, p0 = (size_t)blockIdx.y * kTileP;
+    // linear block number -> (ti, tj) with ti <= tj: row ti of the triangle starts at ti * tiles - ti (ti - 1) / 2
+    const unsigned long long b = blockIdx.x;
+    unsigned long long ti = (unsigned long long)(((2.0 * tiles + 1.0) - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (ti >= tiles) ti = tiles - 1;
+    while (ti > 0 && ti * tiles - ti * (ti - 1) / 2 > b) --ti;
+    while ((ti + 1) * tiles - (ti + 1) * ti / 2 <= b) ++ti;
+    const unsigned long long tj = ti + (b - (ti * tiles - ti * (ti - 1) / 2));
+    const size_t q0 = (size_t)ti * kTileQ, p0 = (size_t)tj * kTileP;
     T acc[4][4];
     compute_tile<T>(X + p0 * ld, ld, X + q0 * ld, ld, dim, true, acc, Qs, Ps, tid, qb, pb);
 #pragma unroll
@@ -390,18 +458,22 @@ __global__ __launch_bounds__(256) void exact_pairwise_kernel(const T *__restrict
         const size_t i = q0 + qb + a;
         if (i >= n) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const size_t j = p0 + pb + b;
-            if (j < n) out[i * n + j] = (i == j) ? (T)0 : pn_sqrt(acc[a][b]);
+        for (int bb = 0; bb < 4; ++bb) {
+            const size_t j = p0 + pb + bb;
+            if (j >= n) continue;
+            const T d = (i == j) ? (T)0 : pn_sqrt(acc[a][bb]);
+            out[i * n + j] = d;
+            if (ti != tj) out[j * n + i] = d;  // the mirrored write of src/distance.rs:69-70
         }
     }
 }
 
 template <typename T>
 static hipError_t launch_exact_pairwise(const T *X, size_t n, int dim, size_t ld, T *out, hipStream_t s) {
-    const unsigned t = (unsigned)(round_up(n, kTileQ) / kTileQ);
-    dim3 grid(t, t), block(256);
-    hipLaunchKernelGGL((exact_pairwise_kernel<T>), grid, block, 0, s, X, n, dim, ld, out);
+    const unsigned long long t = (unsigned long long)(round_up(n, kTileQ) / kTileQ);
+    const unsigned long long blocks = t * (t + 1) / 2;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((exact_pairwise_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, dim, ld, out, (uint32_t)t);
     return hipGetLastError();
 }
 hipError_t launch_exact_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *out, hipStream_t s) {
@@ -446,6 +518,16 @@ __global__ void cosine_pairwise_kernel(const T *__restrict__ X, size_t n, int di
     }
     const T den = norms[i] * norms[j];
     out[i * n + j] = (T)1 - dot / den;
+}
+hipError_t launch_cosine_norms_f32(const float *X, size_t n, int dim, size_t ld, float *norms, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL((cosine_norms_kernel<float>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, X, n, dim, ld, norms);
+    return hipGetLastError();
+}
+hipError_t launch_cosine_norms_f64(const double *X, size_t n, int dim, size_t ld, double *norms, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL((cosine_norms_kernel<double>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, X, n, dim, ld, norms);
+    return hipGetLastError();
 }
 template <typename T>
 static hipError_t launch_cosine_pairwise(const T *X, size_t n, int dim, size_t ld, T *norms, T *out, hipStream_t s) {

@@ -151,6 +151,8 @@ struct pn_index {
     float *d_mu = nullptr;   // translation vector of the bf16 tier: the corpus mean per dimension, or zero
     bool centered = false;   // d_mu != 0: translating shrinks the squared norms at least 16x
     bool bf16_ok = false;
+    int metric = 0;          // 0 Euclidean, 1 Cosine (exact scan only; d_cnorm = the rows' norms in the index's type)
+    void *d_cnorm = nullptr;
     bool bf16_ci = false;    // "norm in the accumulator" image layout (bf16_filter.hip, bf16_ci_dim)
     double bf16_bmax = 0.0, bf16_dmax = 0.0;  // corpus-wide maxima of the bound's per-row constants (CI layout)
     int n_cu = 256;          // workgroups of the persistent MFMA filter = one per CU
@@ -231,6 +233,18 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         HIPCHK(launch_pack_rows_f64((const double *)d_src, ix->n, ix->dim, row_stride, (double *)ix->d_pts,
                                     ix->n_pad, ix->ld, s));
     ix->mfma_ok = false;
+    if (ix->metric == 1) {
+        // Cosine: the rows' norms (sequential sum of squares + sqrt, in T); the filter tiers bound EUCLIDEAN distances
+        // and are not built
+        HIPCHK(hipMalloc(&ix->d_cnorm, ix->n_pad * sizeof(T)));
+        HIPCHK(hipMemsetAsync(ix->d_cnorm, 0, ix->n_pad * sizeof(T), s));
+        if (sizeof(T) == 4)
+            HIPCHK(launch_cosine_norms_f32((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, (float *)ix->d_cnorm, s));
+        else
+            HIPCHK(launch_cosine_norms_f64((const double *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, (double *)ix->d_cnorm, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return PN_OK;
+    }
     if (sizeof(T) == 4) {
         HIPCHK(hipMalloc((void **)&ix->d_norm, ix->n_pad * sizeof(float)));
         uint32_t *d_flag = nullptr;
@@ -335,7 +349,7 @@ static int validate_create(const void *points, size_t n_rows, size_t n_cols, ptr
 
 template <typename T>
 static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
-                            ptrdiff_t col_stride, int device, pn_index **out) {
+                            ptrdiff_t col_stride, int device, pn_index **out, int metric = 0) {
     PNCHK(validate_create(points, n_rows, n_cols, row_stride, col_stride, out));
     PNCHK(check_device(device));
     DeviceGuard g(device);
@@ -344,6 +358,7 @@ static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdi
     if (!ix) return fail(PN_ERR_NOMEM, "host allocation failed");
     ix->device = device;
     ix->elem_bytes = (int)sizeof(T);
+    ix->metric = metric;
     ix->n = n_rows;
     ix->dim = n_cols;
     ix->ld = pick_ld(n_cols);
@@ -388,6 +403,17 @@ extern "C" int pn_index_create_f32(const float *points, size_t n_rows, size_t n_
 extern "C" int pn_index_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
                                    ptrdiff_t col_stride, int device, pn_index **out) {
     return create_from_host<double>(points, n_rows, n_cols, row_stride, col_stride, device, out);
+}
+
+// BallTree::new(points, Cosine) (src/ball_tree.rs:38-63 with src/distance.rs:76-122): same validation; queries are
+// exact scans under Cosine::distance (see the header for how this differs from the reference's pruned walk)
+extern "C" int pn_index_create_cosine_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                          ptrdiff_t col_stride, int device, pn_index **out) {
+    return create_from_host<float>(points, n_rows, n_cols, row_stride, col_stride, device, out, 1);
+}
+extern "C" int pn_index_create_cosine_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                          ptrdiff_t col_stride, int device, pn_index **out) {
+    return create_from_host<double>(points, n_rows, n_cols, row_stride, col_stride, device, out, 1);
 }
 
 extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
@@ -443,6 +469,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_img) (void)hipFree(ix->d_img);
     if (ix->d_mu) (void)hipFree(ix->d_mu);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
+    if (ix->d_cnorm) (void)hipFree(ix->d_cnorm);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     if (ix->sh.tree) host_tree_free(ix->sh.tree);
@@ -531,7 +558,11 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
         // a call that handed more than 1/16 of its queries to the next tier: this corpus defeats the current plan
         // -- widen it, then turn the tier off (sticky; takes effect from the next call on)
         const size_t nf = *r.h_nflag;
+#if !defined(PN_DIAG_BF_NOSLOW) && !defined(PN_DIAG_BF_NOSTORE)  // timing-only builds flag every query by design
         if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
+#else
+        (void)nf;
+#endif
     }
     r.pending = false;
 }
@@ -604,6 +635,8 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
     switch (option) {
         case PN_OPT_ENGINE:
             if (value < PN_ENGINE_AUTO || value > PN_ENGINE_BF16) return fail(PN_ERR_INVALID, "bad engine %lld", (long long)value);
+            if (ix->metric == 1 && value != PN_ENGINE_AUTO && value != PN_ENGINE_EXACT)
+                return fail(PN_ERR_UNSUPPORTED, "a Cosine index is served by the exact scan only");
             if (value == PN_ENGINE_BF16 && !ix->bf16_ok)
                 return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (f64, D > 1024, fewer than 64 rows or out-of-range values)");
             if (value == PN_ENGINE_MFMA && !ix->mfma_ok)
@@ -698,12 +731,15 @@ template <> struct Ops<float> {
     }
     static hipError_t knn(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, int kp,
                           size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
-                          uint32_t no, hipStream_t s) {
-        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, s);
+                          uint32_t no, const float *pn, const float *qn, hipStream_t s) {
+        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s);
+    }
+    static hipError_t cnorms(const float *X, size_t n, int dim, size_t ld, float *o, hipStream_t s) {
+        return launch_cosine_norms_f32(X, n, dim, ld, o, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, hipStream_t s) {
-        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, s);
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s) {
+        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s);
     }
 };
 template <> struct Ops<double> {
@@ -712,12 +748,15 @@ template <> struct Ops<double> {
     }
     static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
                           size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
-                          uint32_t no, hipStream_t s) {
-        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, s);
+                          uint32_t no, const double *pn, const double *qn, hipStream_t s) {
+        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s);
+    }
+    static hipError_t cnorms(const double *X, size_t n, int dim, size_t ld, double *o, hipStream_t s) {
+        return launch_cosine_norms_f64(X, n, dim, ld, o, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, hipStream_t s) {
-        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, s);
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s) {
+        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s);
     }
 };
 
@@ -728,7 +767,7 @@ template <> struct Ops<double> {
 template <typename T>
 static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
                      uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s, bool second_tier,
-                     const uint32_t *nq_dev, uint32_t nq_off, CallRec *rec) {
+                     const uint32_t *nq_dev, uint32_t nq_off, CallRec *rec, const T *qnorm = nullptr) {
     using KeyT = typename KeyOf<T>::type;
     // k beyond one candidate buffer (960 slots): rounds of <= 960 neighbours, each resuming strictly
     // after the last (distance key, row) of the previous one
@@ -762,10 +801,11 @@ static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, 
     for (size_t done = 0; done < kout; done += kRound) {
         const size_t kr = kout - done < kRound ? kout - done : kRound;
         HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kr, pl.seg_len, cb,
-                           done ? lo_key : nullptr, done ? lo_idx : nullptr, nq_dev, nq_off, s));
+                           done ? lo_key : nullptr, done ? lo_idx : nullptr, nq_dev, nq_off,
+                           qnorm ? (const T *)ix->d_cnorm : nullptr, qnorm, s));
         if (prof && done == 0) HIPCHK(hipEventRecord(rec->ev[1], s));
         HIPCHK(Ops<T>::select(cb, (int)nq, (int)kr, ix->index_base, d_idx, d_dist, out_stride, done, lo_key, lo_idx,
-                              nq_dev, nq_off, s));
+                              nq_dev, nq_off, qnorm != nullptr, s));
     }
     return PN_OK;
 }
@@ -1179,6 +1219,13 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
         T *od = d_dist + qs * out_stride;
         bool use_mfma = false, use_bf16 = false;
         Bf16Plan bplan{};
+        const T *qnorm = nullptr;
+        if (ix->metric == 1) {  // Cosine: each query's norm over ITS OWN length (src/distance.rs:92-97), not the zip's
+            PNCHK(ws.w_qnorm.ensure(nq_pad * sizeof(T)));
+            HIPCHK(hipMemsetAsync(ws.w_qnorm.p, 0, nq_pad * sizeof(T), s));
+            HIPCHK(Ops<T>::cnorms(d_q + qs * q_stride, nqc, (int)q_cols, q_stride, (T *)ws.w_qnorm.p, s));
+            qnorm = (const T *)ws.w_qnorm.p;
+        }
         if constexpr (sizeof(T) == 4) {
             if (ix->mfma_ok && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && ix->engine != PN_ENGINE_BF16) {
                 // the filter keeps kp = kout + margin candidates per (segment, query) in <= 256 slots
@@ -1208,7 +1255,7 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
             }
         }
         if (!use_bf16 && !use_mfma)
-            PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec));
+            PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec, qnorm));
         if (rec->prof) HIPCHK(hipEventRecord(rec->ev[3], s));
         PNCHK(rec_end(ix, rec, s));
     }
@@ -1403,15 +1450,15 @@ template <typename T> struct RadOps;
 template <> struct RadOps<float> {
     static hipError_t run(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, float r,
                           size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offs, uint64_t *fill,
-                          uint64_t base, hipStream_t s) {
-        return launch_exact_radius_f32(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, s);
+                          uint64_t base, const float *pn, const float *qn, hipStream_t s) {
+        return launch_exact_radius_f32(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, pn, qn, s);
     }
 };
 template <> struct RadOps<double> {
     static hipError_t run(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, double r,
                           size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offs, uint64_t *fill,
-                          uint64_t base, hipStream_t s) {
-        return launch_exact_radius_f64(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, s);
+                          uint64_t base, const double *pn, const double *qn, hipStream_t s) {
+        return launch_exact_radius_f64(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offs, fill, base, pn, qn, s);
     }
 };
 
@@ -1422,7 +1469,7 @@ template <> struct RadOps<double> {
 // entries, *out a malloc'ed array of offs[nq] global row numbers, ascending per query
 template <typename T>
 static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t nq_pad, size_t dim_eff, T radius,
-                        std::vector<uint64_t> &offs, uint64_t **out, hipStream_t s) {
+                        std::vector<uint64_t> &offs, uint64_t **out, hipStream_t s, const T *qnorm = nullptr) {
     *out = nullptr;
     uint32_t *d_counts = nullptr;
     uint64_t *d_offs = nullptr, *d_fill = nullptr;
@@ -1438,7 +1485,8 @@ static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t n
         }
         if (hipMemsetAsync(d_counts, 0, cells * 4, s) != hipSuccess ||
             RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
-                           pl.nseg, d_counts, nullptr, nullptr, ix->index_base, s) != hipSuccess) {
+                           pl.nseg, d_counts, nullptr, nullptr, ix->index_base, qnorm ? (const T *)ix->d_cnorm : nullptr,
+                           qnorm, s) != hipSuccess) {
             rc = fail(PN_ERR_DEVICE, "radius count pass failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
@@ -1470,7 +1518,8 @@ static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t n
         if (hipMalloc((void **)&d_fill, run * 8) != hipSuccess) { rc = fail(PN_ERR_NOMEM, "hipMalloc radius output failed"); break; }
         if (hipMemcpyAsync(d_offs, h_offs.data(), cells * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
             RadOps<T>::run((const T *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qp, (int)nq, ix->ld, radius, pl.seg_len,
-                           pl.nseg, d_counts, d_offs, d_fill, ix->index_base, s) != hipSuccess ||
+                           pl.nseg, d_counts, d_offs, d_fill, ix->index_base, qnorm ? (const T *)ix->d_cnorm : nullptr, qnorm,
+                           s) != hipSuccess ||
             hipMemcpyAsync(h_out, d_fill, run * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) {
             rc = fail(PN_ERR_DEVICE, "radius fill pass failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1750,8 +1799,19 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
                 ix->sh.stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
             }
         }
+        const T *qnorm = nullptr;
+        if (ix->metric == 1) {  // Cosine: the queries' norms over their own length
+            rc = ws.w_qnorm.ensure(nq_pad * sizeof(T));
+            if (rc != PN_OK) break;
+            if (hipMemsetAsync(ws.w_qnorm.p, 0, nq_pad * sizeof(T), s) != hipSuccess ||
+                Ops<T>::cnorms((const T *)ws.w_hq.p, nq, (int)q_cols, q_cols ? q_cols : 1, (T *)ws.w_qnorm.p, s) != hipSuccess) {
+                rc = fail(PN_ERR_DEVICE, "query norms failed");
+                break;
+            }
+            qnorm = (const T *)ws.w_qnorm.p;
+        }
         std::vector<uint64_t> offs;
-        rc = radius_exact<T>(ix, ws, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s);
+        rc = radius_exact<T>(ix, ws, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s, qnorm);
         if (rc != PN_OK) break;
         memcpy(offsets, offs.data(), (nq + 1) * sizeof(uint64_t));
     } while (0);
@@ -1772,6 +1832,43 @@ extern "C" void pn_free(void *p) { free(p); }
 // ---------------------------------------------------------------------------
 // pairwise
 // ---------------------------------------------------------------------------
+// distance::pairwise with input and output in HBM (extension: the reference returns a host Array2): d_x row-major
+// [n][cols] with row stride >= cols, d_out [n][n]; enqueued on `stream`, nothing is copied or waited for except the
+// padded working copy of the rows, which is released when the stream has passed it.
+template <typename T>
+static int pairwise_device_impl(const T *d_x, size_t n, size_t cols, size_t row_stride, int device, T *d_out,
+                                hipStream_t s) {
+    if (n == 0) return PN_OK;
+    if (!d_out) return fail(PN_ERR_INVALID, "out is NULL");
+    if (!d_x && cols) return fail(PN_ERR_INVALID, "x is NULL");
+    PNCHK(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    if (n < 2) {  // src/distance.rs:63-65
+        HIPCHK(hipMemsetAsync(d_out, 0, n * n * sizeof(T), s));
+        return PN_OK;
+    }
+    const size_t ld = pick_ld(cols), n_pad = round_up(n, (size_t)kRowPad);
+    T *d_p = nullptr;
+    HIPCHK(hipMalloc((void **)&d_p, n_pad * ld * sizeof(T)));
+    hipError_t e = Ops<T>::pack(d_x, n, cols, row_stride ? row_stride : 1, d_p, n_pad, ld, s);
+    if (e == hipSuccess)
+        e = (sizeof(T) == 4) ? launch_exact_pairwise_f32((const float *)d_p, n, (int)cols, ld, (float *)d_out, s)
+                             : launch_exact_pairwise_f64((const double *)d_p, n, (int)cols, ld, (double *)d_out, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the working copy must outlive the kernel
+    (void)hipFree(d_p);
+    if (e != hipSuccess) return fail(PN_ERR_DEVICE, "pairwise: %s", hipGetErrorString(e));
+    return PN_OK;
+}
+extern "C" int pn_pairwise_device_f32(const float *d_x, size_t n, size_t cols, size_t row_stride, int device,
+                                      float *d_out, void *stream) {
+    return pairwise_device_impl<float>(d_x, n, cols, row_stride, device, d_out, (hipStream_t)stream);
+}
+extern "C" int pn_pairwise_device_f64(const double *d_x, size_t n, size_t cols, size_t row_stride, int device,
+                                      double *d_out, void *stream) {
+    return pairwise_device_impl<double>(d_x, n, cols, row_stride, device, d_out, (hipStream_t)stream);
+}
+
 template <typename T>
 static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride, int device, T *out,
                          bool cosine = false) {

@@ -68,21 +68,27 @@ inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 // lo_key/lo_idx (nullable, [nq_pad]): only entries strictly after (lo_key[q], lo_idx[q]) take part
 // nq_dev (nullable) / nq_off: device-driven query count -- only the first min(nq, max(*nq_dev - nq_off, 0)) queries
 // exist; the grid is sized for nq and the surplus query tiles exit at once (second tier behind a filter)
+// pnorm / qnorm (nullable, together): the index's metric is Cosine -- distance = 1 - dot / (qnorm[q] pnorm[row])
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const float *pnorm,
+                                const float *qnorm, hipStream_t s);
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
-                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const double *pnorm,
+                                const double *qnorm, hipStream_t s);
 // radius: count pass (fill == nullptr) then fill pass.  counts/offsets are [query][seg].
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
-                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base,
-                                   hipStream_t s);
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const float *pnorm,
+                                   const float *qnorm, hipStream_t s);
 hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                    size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
-                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base,
-                                   hipStream_t s);
+                                   const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const double *pnorm,
+                                   const double *qnorm, hipStream_t s);
+// Cosine's norms: norms[i] = sqrt(sequential sum of x_i[k]^2, k < dim) in T
+hipError_t launch_cosine_norms_f32(const float *X, size_t n, int dim, size_t ld, float *norms, hipStream_t s);
+hipError_t launch_cosine_norms_f64(const double *X, size_t n, int dim, size_t ld, double *norms, hipStream_t s);
 hipError_t launch_exact_pairwise_f32(const float *X, size_t n, int dim, size_t ld, float *out, hipStream_t s);
 hipError_t launch_exact_pairwise_f64(const double *X, size_t n, int dim, size_t ld, double *out, hipStream_t s);
 // distance::pairwise under the Cosine metric; norms: n elements of scratch
@@ -97,10 +103,12 @@ hipError_t launch_cosine_pairwise_f64(const double *X, size_t n, int dim, size_t
 // records the last (key, row) written per query as the next round's lower bound
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
+                                   hipStream_t s);
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
+                                   hipStream_t s);
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).

@@ -19,6 +19,13 @@ __device__ __forceinline__ uint64_t sel_key(double d) {
 }
 __device__ __forceinline__ float key_to_dist(uint32_t k) { return __uint_as_float(k); }
 __device__ __forceinline__ double key_to_dist(uint64_t k) { return __longlong_as_double((long long)k); }
+// inverse of dist_key_signed (exact_scan.hip): keys of a Cosine index
+__device__ __forceinline__ float key_to_dist_signed(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ double key_to_dist_signed(uint64_t k) {
+    return __longlong_as_double((long long)((k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
 
 // rank of entry e among n LDS entries under (key, idx); one lane per entry
 template <typename KeyT, typename IdxT>
@@ -103,7 +110,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
                                                           size_t out_stride, size_t out_off,
                                                           typename KeyOf<T>::type *__restrict__ lo_key,
                                                           uint32_t *__restrict__ lo_idx,
-                                                          const uint32_t *__restrict__ nq_dev, uint32_t nq_off) {
+                                                          const uint32_t *__restrict__ nq_dev, uint32_t nq_off,
+                                                          int signed_keys) {
     using KeyT = typename KeyOf<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
             idx_out[q * out_stride + out_off + r] = index_base + ix;
-            dist_out[q * out_stride + out_off + r] = key_to_dist(k);
+            dist_out[q * out_stride + out_off + r] = signed_keys ? key_to_dist_signed(k) : key_to_dist(k);
             if (lo_key && r == (uint32_t)kout - 1) {  // next round resumes strictly after this entry
                 lo_key[q] = k;
                 lo_idx[q] = ix;
@@ -152,27 +160,30 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
 template <typename T>
 static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                       T *dist_out, int kp_bound, size_t out_stride, size_t out_off, void *lo_key,
-                                      uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                      uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
+                                      hipStream_t s) {
     using KeyT = typename KeyOf<T>::type;
     const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
                        index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx, nq_dev,
-                       nq_off);
+                       nq_off, signed_keys ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
+                                   hipStream_t s) {
     return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                      lo_key, lo_idx, nq_dev, nq_off, s);
+                                      lo_key, lo_idx, nq_dev, nq_off, signed_keys, s);
 }
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
-                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                   uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
+                                   hipStream_t s) {
     return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                       lo_key, lo_idx, nq_dev, nq_off, s);
+                                       lo_key, lo_idx, nq_dev, nq_off, signed_keys, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -66,9 +66,9 @@ class Euclidean:
 
 class Cosine:
     """``distance::Cosine`` (src/distance.rs:76-122): ``1 - dot / (|x1| |x2|)`` with the reference's three
-    sequential sums; ``rdistance`` and both conversions are the identity there.  Served as a pair metric and by
-    ``pairwise``; ``BallTree.new(points, Cosine())`` is not offered (cosine distance is not a metric: the reference's
-    pruned walk returns walk-dependent answers under it, and this engine replaces that walk)."""
+    sequential sums; ``rdistance`` and both conversions are the identity there.  Served as a pair metric, by
+    ``pairwise`` and as the metric of ``BallTree.new(points, Cosine())`` -- there as an EXACT scan: cosine distance is
+    not a metric, so the reference's ball-pruned walk may skip true neighbours under it; this engine never does."""
 
     def __eq__(self, other):
         return isinstance(other, Cosine)
@@ -95,6 +95,22 @@ class Cosine:
 
     def distance_to_rdistance(self, d):  # src/distance.rs:118-121
         return d
+
+
+def pairwise_device(x, out=None):
+    """``distance::pairwise(x, &Euclidean)`` with rows and the n x n result in HBM (torch CUDA tensors; extension)."""
+    import torch
+    if not x.is_cuda or x.dim() != 2 or x.dtype not in (torch.float32, torch.float64) or (x.shape[1] > 1 and x.stride(1) != 1):
+        raise ValueError("x must be a row-major 2-D float32/float64 CUDA tensor")
+    n, d = x.shape
+    if out is None:
+        out = torch.empty((n, n), dtype=x.dtype, device=x.device)
+    sfx = "f32" if x.dtype == torch.float32 else "f64"
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    check(getattr(_lib.lib(), f"pn_pairwise_device_{sfx}")(x.data_ptr() if n * d else None, n, d,
+                                                           x.stride(0) if n > 1 else max(d, 1), x.device.index or 0,
+                                                           out.data_ptr(), C.c_void_p(st)))
+    return out
 
 
 def pairwise(x, metric=None, device: int = 0):

@@ -431,4 +431,68 @@ def test_cosine_metric_and_pairwise_vs_oracle(pn, oracle_mod, kats, dtype):
     a, b = uniform((9,), 1, dtype), uniform((5,), 2, dtype)
     assert m.distance(a, b).tobytes() == oracle_mod.cosine(a, b).tobytes()
     with pytest.raises(NotImplementedError):
-        pn.BallTree.new(uniform((10, 3), 3, dtype), m)
+        pn.BallTree.new(uniform((10, 3), 3, dtype), object())
+
+
+def _cosine_brute(oracle_mod, pts, qs, k):
+    """k smallest (Cosine::distance, index) per query from the oracle's pairwise(x, &Cosine) over [queries; points]"""
+    nq = len(qs)
+    d = oracle_mod.pairwise_cosine(np.vstack([qs, pts]))[:nq, nq:]
+    idx = np.empty((nq, min(k, len(pts))), dtype=np.uint64)
+    dist = np.empty(idx.shape, dtype=pts.dtype)
+    for a in range(nq):
+        nan = np.isnan(d[a])  # ordered-float: NaN greatest; cosine distances may be a few ulp below zero
+        order = np.lexsort((np.arange(len(pts)), np.where(nan, np.inf, d[a]), nan))[: idx.shape[1]]
+        idx[a], dist[a] = order, d[a][order]
+    return idx, dist
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,dim,nq,k", [(3000, 24, 40, 7), (500, 3, 30, 500), (70, 130, 9, 5), (5000, 128, 64, 10)])
+def test_ball_tree_under_cosine_is_an_exact_scan(pn, oracle_mod, dtype, n, dim, nq, k):
+    """BallTree::new(points, Cosine): k smallest Cosine::distance in the reference's arithmetic (src/distance.rs:85-107),
+    against the oracle's pairwise(x, &Cosine) bit for bit -- k-NN, nearest, radius (the deviation from the reference's
+    pruned walk is documented at pn_index_create_cosine_*)."""
+    pts = uniform((n, dim), 700 + n, dtype) - dtype(0.3)
+    pts[3] = 0  # a zero row: its distance to anything is NaN and sorts last
+    qs = np.concatenate([pts[10:13] * dtype(2.0), uniform((nq - 3, dim), 701 + n, dtype) - dtype(0.3)])
+    tree = pn.BallTree.new(pts, pn.distance.Cosine())
+    assert tree.metric == pn.distance.Cosine() and not tree.bf16_eligible and not tree.mfma_eligible
+    want_i, want_d = _cosine_brute(oracle_mod, pts, qs, k)
+    gi, gd = tree.query_batch(qs, k)
+    assert _same_dist(gd, want_d), "cosine distances differ"
+    fin = ~np.isnan(want_d)
+    assert np.array_equal(gi[fin], want_i[fin])
+    i0, d0 = tree.query_nearest(qs[5])
+    assert i0 == int(want_i[5, 0]) and d0.tobytes() == want_d[5, 0].tobytes()
+    dall = oracle_mod.pairwise_cosine(np.vstack([qs, pts]))[:nq, nq:]
+    r = dtype(np.sort(dall[4])[min(6, n - 1)])
+    off, ids = tree.query_radius_batch(qs, r)
+    for a in range(nq):
+        assert np.array_equal(ids[int(off[a]):int(off[a + 1])], np.nonzero(dall[a] < r)[0].astype(np.uint64)), a
+    with pytest.raises(pn.PetalError):
+        tree.set_engine("bf16")
+    # zip truncation: a shorter query uses the rows' full norms and its own
+    if dim > 4:
+        qi, qd = tree.query(qs[7][: dim - 2], 3)
+        m = pn.distance.Cosine()
+        allv = np.array([m.distance(qs[7][: dim - 2], p) for p in pts])
+        keep = ~np.isnan(allv)
+        best = np.lexsort((np.arange(n)[keep], allv[keep]))[:3]
+        assert np.array_equal(qi, np.arange(n)[keep][best].astype(np.uint64)) and _same_dist(qd, allv[keep][best])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pairwise_symmetric_tiles_and_device_entry(pn, oracle_mod, dtype):
+    """distance::pairwise at a size with many tiles (the upper triangle of 64 x 64 tiles is computed, each pair
+    written twice), host entry and HBM-resident entry, against the oracle bit for bit."""
+    import torch
+    for n, dim in ((1000, 33), (257, 128), (65, 3)):
+        x = uniform((n, dim), 900 + n, dtype)
+        want = oracle_mod.pairwise(x)
+        got = pn.distance.pairwise(x, pn.distance.Euclidean())
+        assert got.tobytes() == want.tobytes(), (n, dim)
+        xd = torch.from_numpy(x).to("cuda:0")
+        gd = pn.distance.pairwise_device(xd)
+        torch.cuda.synchronize()
+        assert gd.cpu().numpy().tobytes() == want.tobytes(), (n, dim)
