@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "petal_neighbors.hpp"
 
@@ -72,6 +73,43 @@ int main(int argc, char **argv) {
     petal::BallTree<float> tf = petal::BallTree<float>::euclidean(x, 2, 2);
     auto rf = tf.query(x, 2, 9);
     EXPECT(rf.first.size() == 2 && rf.first[0] == 0 && rf.second[0] == 0.f && rf.second[1] == 5.f);
+    // ---- VantagePointTree: euclidian (src/vantage_point_tree.rs:220-233)
+    const double p6[] = {1., 2., 1.1, 2.2, 0.9, 1.9, 1., 2.1, -2., 3., -2.2, 3.1};
+    auto vp = petal::VantagePointTree<double>::euclidean(p6, 6, 2);
+    const double qv[] = {0.95, 1.96};
+    EXPECT(vp.query_nearest(qv, 2).first == 0);
+    try { petal::VantagePointTree<double>::euclidean(nullptr, 0, 2); EXPECT(false); }
+    catch (const ArrayError &e) { EXPECT(e.kind == ArrayError::Empty); }
+    // ---- tree introspection (src/ball_tree.rs:296-353) on node_init's vector (:784-798): centroid [0,4], radius 5
+    const double pn3[] = {0., 1., 0., 9., 0., 2.};
+    Tree ti = Tree::euclidean(pn3, 3, 2);
+    EXPECT(ti.num_nodes() == 3 && ti.radius_of(0) == 5.0);
+    EXPECT(ti.children_of(0).some && ti.children_of(0).left == 1 && ti.children_of(0).right == 2 && !ti.children_of(1).some);
+    EXPECT(ti.points_of(0).size() == 3 && ti.points_of(1).size() == 1 && ti.points_of(2).size() == 2);
+    EXPECT(ti.compare_nodes(0, 1) == 1 && ti.compare_nodes(1, 1) == 0 && ti.node_distance_lower_bound(0, 0) == 0.0);
+    try { ti.radius_of(3); EXPECT(false); }
+    catch (const petal::DeviceError &e) { EXPECT(e.code == PN_ERR_INVALID); }
+    // ---- BallTree::new(points, Cosine): cosine (src/distance.rs:143-182) neighbours by an exact scan
+    const double pc[] = {1., 0., 0., 1., 1., 1., -1., 0.};
+    auto tc = petal::BallTree<double, petal::distance::Cosine>::create(pc, 4, 2);
+    const double qc[] = {2., 0.1};
+    auto rc = tc.query(qc, 2, 4);
+    petal::distance::Cosine cm;
+    EXPECT(rc.first.size() == 4 && rc.first[0] == 0 && rc.first[1] == 2 && rc.first[3] == 3);
+    for (size_t j = 0; j < 4; ++j) EXPECT(rc.second[j] == cm.distance(qc, pc + 2 * rc.first[j], 2));
+    // ---- row shards through the ABI: three virtual shards on GPU 0, one RCCL all-gather, merged = unsharded
+    {
+        std::vector<float> big(3000 * 8), qs(8);
+        unsigned s = 12345u;
+        for (float &v : big) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8) * (1.0f / 16777216.0f); }
+        for (float &v : qs) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8) * (1.0f / 16777216.0f); }
+        petal::ShardedBallTree sh(big.data(), 3000, 8, {0, 0, 0});
+        petal::BallTree<float> one = petal::BallTree<float>::euclidean(big.data(), 3000, 8);
+        auto a1 = sh.query(qs.data(), 8, 7);
+        auto a2 = one.query(qs.data(), 8, 7);
+        EXPECT(a1.first == a2.first && a1.second == a2.second);
+        EXPECT(sh.query_radius(qs.data(), 8, a2.second[3]) == one.query_radius(qs.data(), 8, a2.second[3]));
+    }
     std::printf("%s\n", fails ? "FAILED" : "ok");
     return fails;
 }
