@@ -119,13 +119,14 @@ struct Workspace {
     DevBuf w_q, w_qnorm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_misc, w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
     DevBuf w_bq, w_qn, w_qbad, w_gq, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
     DevBuf w_hq, w_hidx, w_hdist;  // staging of the host entry points (queries up, results down)
+    DevBuf w_fparts;               // second tier, many-segment path: per-group partial results
     hipStream_t stream = nullptr;  // the host entry points run here
     hipEvent_t done = nullptr;
     hipStream_t last_stream = nullptr;
     bool in_flight = false;
-    DevBuf *all[27] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
+    DevBuf *all[28] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
                        &w2_cnt, &w2_tau, &w_lo, &w_bq, &w_qn, &w_qbad, &w_gq, &w_gidx, &w_gdist, &w_gsel, &w_seed,
-                       &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist};
+                       &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist, &w_fparts};
 };
 
 // What a finished chunk of a call leaves for the host to pick up LATER (never inside the call): hipEvent brackets of
@@ -815,6 +816,7 @@ static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, 
 // unconditionally and driven by the device-side count, so the host never waits to learn whether anything was flagged
 // (with nothing flagged every kernel here exits at once).  Rounds of kSecondTierRows queries bound the scratch.
 constexpr size_t kSecondTierRows = 16384;
+constexpr size_t kSecondTierFew = 256;  // the first flagged queries of a chunk take the many-segment path below
 static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kout,
                              const uint32_t *d_flags, uint32_t *d_nsel, uint64_t *d_idx, float *d_dist,
                              size_t out_stride, hipStream_t s) {
@@ -824,7 +826,44 @@ static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp,
     PNCHK(ws.w_gidx.ensure(F * kout * sizeof(uint64_t)));
     PNCHK(ws.w_gdist.ensure(F * kout * sizeof(float)));
     HIPCHK(launch_compact_flags(d_flags, (int)nq, (uint32_t *)ws.w_gsel.p, d_nsel, s));
-    for (size_t off = 0; off < nq; off += F) {
+    size_t first = 0;
+    // Few flagged queries are the normal case, and they share ONE 64-query tile: with the usual <= 32 segments that is
+    // <= 32 workgroups for the whole corpus (10M rows: 0.4 s for a single flagged query).  So the first 256 flagged
+    // queries of a chunk are scanned with up to 512 row segments -- every CU busy -- and selected in two levels:
+    // groups of 16 segments to a part each, then the (distance, index) merge of the parts (the shard-merge kernel).
+    const size_t by_rows = (ix->n + 4095) / 4096;
+    if (kout <= 192 && by_rows >= 16) {
+        const size_t Ff = nq < kSecondTierFew ? nq : kSecondTierFew, Ff_pad = kSecondTierFew;
+        const int cap = pick_cap(kout);
+        size_t groups = by_rows / 16 < 32 ? by_rows / 16 : 32;
+        while (groups > 1 && groups * kout * 12 > 60 * 1024) --groups;  // the merge kernel's LDS
+        const size_t nseg = groups * 16;
+        size_t seg_len = round_up((ix->n + nseg - 1) / nseg, (size_t)kRowPad);
+        // (a last segment that starts beyond the corpus scans nothing and leaves an empty cell)
+        const size_t cells = nseg * Ff_pad, slots = cells * (size_t)cap;
+        PNCHK(ws.w2_keys.ensure(slots * sizeof(uint32_t)));
+        PNCHK(ws.w2_idx.ensure(slots * sizeof(uint32_t)));
+        PNCHK(ws.w2_cnt.ensure(cells * sizeof(uint32_t)));
+        PNCHK(ws.w2_tau.ensure(cells * sizeof(uint32_t)));
+        PNCHK(ws.w_fparts.ensure(groups * Ff_pad * kout * (sizeof(uint64_t) + sizeof(float))));
+        uint64_t *p_idx = (uint64_t *)ws.w_fparts.p;
+        float *p_dist = (float *)(p_idx + groups * Ff_pad * kout);
+        CandBuf cb{ws.w2_keys.p, (uint32_t *)ws.w2_idx.p, (uint32_t *)ws.w2_cnt.p, ws.w2_tau.p, Ff_pad, (int)nseg, cap};
+        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, d_nsel, 0, (uint32_t)Ff, (float *)ws.w_gq.p, s));
+        HIPCHK(launch_exact_knn_f32((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, (const float *)ws.w_gq.p, (int)Ff,
+                                    ix->ld, (int)kout, seg_len, cb, nullptr, nullptr, d_nsel, 0, nullptr, nullptr, s));
+        CandBuf cg = cb;
+        cg.nseg = 16;
+        HIPCHK(launch_select_exact_groups_f32(cg, (int)groups, (int)kout, (int)Ff, (int)kout, ix->index_base, p_idx, p_dist,
+                                              Ff_pad * kout, d_nsel, 0, s));
+        HIPCHK(launch_merge_topk_f32(p_idx, p_dist, (int)groups, Ff_pad * kout, Ff_pad * kout, (int)Ff, (int)kout, (int)kout,
+                                     (uint64_t *)ws.w_gidx.p, (float *)ws.w_gdist.p, s, d_nsel));
+        HIPCHK(launch_scatter_results_f32((const uint64_t *)ws.w_gidx.p, (const float *)ws.w_gdist.p,
+                                          (const uint32_t *)ws.w_gsel.p, d_nsel, 0, (uint32_t)Ff, (int)kout, d_idx, d_dist,
+                                          out_stride, s));
+        first = Ff;
+    }
+    for (size_t off = first; off < nq; off += F) {
         const size_t fr = nq - off < F ? nq - off : F;
         HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, d_nsel, (uint32_t)off, (uint32_t)fr,
                                       (float *)ws.w_gq.p, s));
@@ -995,6 +1034,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     p.n_wg = (int)n_wg;
     // rows whose bound lies below the k-th neighbour's distance: ~1.2 k on benign data once the vectors are
     // translated by the corpus mean (measured: 11.8 for k = 10, 116 for k = 100); planned with a margin
+    // (norm-in-accumulator layout: the per-query error constant uses the corpus maxima -- measured 23 / 237 rows for
+    // k = 10 / 100 against 20 / 185 with per-row constants.  Planning for that costs more in candidates (C2: +5 % step
+    // time) than the few extra unproven queries cost in the second tier, so R stays.)
     const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
     size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
     if (per_tile < 1) per_tile = 1;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
                                                           typename KeyOf<T>::type *__restrict__ lo_key,
                                                           uint32_t *__restrict__ lo_idx,
                                                           const uint32_t *__restrict__ nq_dev, uint32_t nq_off,
-                                                          int signed_keys) {
+                                                          int signed_keys, size_t out_group_stride) {
     using KeyT = typename KeyOf<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -120,6 +120,13 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         const uint32_t tot = *nq_dev;
         if (q >= (size_t)(tot > nq_off ? tot - nq_off : 0u)) return;
     }
+    // blockIdx.y = segment group (two-level selection over many segments): group g selects among segments
+    // [g nseg, (g+1) nseg) into its own output part
+    ckey += (size_t)blockIdx.y * (size_t)nseg * nq_pad * (size_t)cap;
+    cidx += (size_t)blockIdx.y * (size_t)nseg * nq_pad * (size_t)cap;
+    ccnt += (size_t)blockIdx.y * (size_t)nseg * nq_pad;
+    idx_out += (size_t)blockIdx.y * out_group_stride;
+    dist_out += (size_t)blockIdx.y * out_group_stride;
     int total_cap = 0;
     for (int s = 0; s < nseg; ++s) total_cap += (int)ccnt[(size_t)s * nq_pad + q];
     KeyT *skey = reinterpret_cast<KeyT *>(smem);
@@ -161,15 +168,25 @@ template <typename T>
 static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                       T *dist_out, int kp_bound, size_t out_stride, size_t out_off, void *lo_key,
                                       uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                      hipStream_t s) {
+                                      hipStream_t s, int groups = 1, size_t out_group_stride = 0) {
     using KeyT = typename KeyOf<T>::type;
+    // cb.nseg = segments per group; every cell holds at most kp_bound entries
     const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
     if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq), dim3(64), sh, s,
+    hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq, (unsigned)groups), dim3(64), sh, s,
                        static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
                        index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx, nq_dev,
-                       nq_off, signed_keys ? 1 : 0);
+                       nq_off, signed_keys ? 1 : 0, out_group_stride);
     return hipGetLastError();
+}
+// two-level selection, first level: `groups` groups of cb.nseg segments each (cb describes group 0, the groups follow
+// each other in the candidate buffers); group g's top kout of every query to idx_out/dist_out + g * out_group_stride.
+// kp: entries a cell holds at most (the scan kernel's final compaction leaves <= its kp)
+hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
+                                          uint64_t *idx_out, float *dist_out, size_t out_group_stride,
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+    return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, kp, (size_t)kout, 0, nullptr, nullptr,
+                                      nq_dev, nq_off, false, s, groups, out_group_stride);
 }
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
@@ -554,10 +571,12 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
                                                         const float *__restrict__ dist_parts, int n_parts,
                                                         size_t idx_part_stride, size_t dist_part_stride, int nq,
                                                         int k_part, int k_out, uint64_t *__restrict__ idx_out,
-                                                        float *__restrict__ dist_out) {
+                                                        float *__restrict__ dist_out,
+                                                        const uint32_t *__restrict__ nq_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+    if (nq_dev && q >= (size_t)*nq_dev) return;  // device-driven query count (second tier, index.hip)
     uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
     uint64_t *sidx = reinterpret_cast<uint64_t *>(smem);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
@@ -593,11 +612,11 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
 
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
-                                 uint64_t *idx_out, float *dist_out, hipStream_t s) {
+                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev) {
     const size_t sh = (size_t)n_parts * k_part * 12;
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
-                       idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out);
+                       idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev);
     return hipGetLastError();
 }
 

@@ -278,3 +278,21 @@ def test_heterogeneous_norms_keep_the_per_row_layout(pn, oracle_mod):
     idx, dist = tree.query_batch(qs, 10)
     oi, od = oracle_mod.brute_knn(pts, qs, 10)
     assert dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_second_tier_many_segment_path(pn, oracle_mod, k):
+    """The device-driven second tier: with k' = k the first tier's proofs fail for a good part of the queries; the
+    first 256 flagged ones of the call take the many-segment scan with the two-level selection (corpus >= 65 536
+    rows), the rest the rounds of the ordinary exact engine -- answers are the oracle's either way."""
+    from petal_neighbors_amd import _lib
+    pts = uniform((90000, 64), 41)
+    qs = uniform((1500, 64), 42)
+    tree, st = _check(pn, oracle_mod, pts, qs, k, opts={_lib.PN_OPT_FILTER_SLOTS: k, _lib.PN_OPT_SEGMENTS: 1})
+    assert st["fallback_queries"] > 300, st
+    # and a handful only: ties beyond k' on duplicated rows
+    pts2 = pts.copy()
+    pts2[1000:1040] = pts2[7]
+    q2 = np.concatenate([pts2[7:8], qs[:200]])
+    tree, st = _check(pn, oracle_mod, pts2, q2, 10)
+    assert 1 <= st["fallback_queries"] <= 8, st
