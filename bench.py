@@ -50,6 +50,8 @@ CONFIGS = {
     "c2s8": (125_000, 128, 10_000, 10),
     "c5m": (1_000_000, 96, 200_000, 10),         # many queries: one workgroup per query tile
     "c3m": (1_000_000, 128, 200_000, 100),
+    "d64": (1_000_000, 64, 10_000, 10),          # narrower rows (kernel experiments)
+    "d64k100": (1_000_000, 64, 10_000, 100),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2516.8  # same table: dense BF16 MFMA = 16 x the f32 matrix rate ("~2.5 PF dense")

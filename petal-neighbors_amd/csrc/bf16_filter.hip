@@ -413,12 +413,61 @@ __device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, i
 // (Round 1 tagged every bound with its register number first -- one v_and_or_b32 each, 2/3 of the fast path's vector
 // work -- so that the rare path needed no search; with seeded thresholds the rare path is rare enough to search.)
 // CI: the chain starts from c0 (the 16 row norms of this lane's rows) instead of zero.
+#ifdef PN_DIAG_KLA  // timing experiments: fragment lookahead
+constexpr int kLA = PN_DIAG_KLA;
+#else
 constexpr int kLA = 3;
+#endif
 constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
-template <int KS, bool CI>
+// smallest (mn) and second smallest (sec) of 16 finite values: triples give (min3, med3); the second smallest overall
+// is the smaller of {second smallest of the triples' minima, the smallest of the triples' medians} -- 21 instructions.
+__device__ __forceinline__ void bf_min2(const f32x16 &v, float &mn, float &sec) {
+    const float big = 3.4e38f;
+    auto lo3 = [](float a, float b, float c) { return fminf(fminf(a, b), c); };
+    auto md3 = [](float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); };
+    const float l0 = lo3(v[0], v[1], v[2]), d0 = md3(v[0], v[1], v[2]);
+    const float l1 = lo3(v[3], v[4], v[5]), d1 = md3(v[3], v[4], v[5]);
+    const float l2 = lo3(v[6], v[7], v[8]), d2 = md3(v[6], v[7], v[8]);
+    const float l3 = lo3(v[9], v[10], v[11]), d3 = md3(v[9], v[10], v[11]);
+    const float l4 = lo3(v[12], v[13], v[14]), d4 = md3(v[12], v[13], v[14]);
+    const float l5 = v[15];
+    const float a = lo3(l0, l1, l2), am = md3(l0, l1, l2);
+    const float b = lo3(l3, l4, l5), bm = md3(l3, l4, l5);
+    mn = fminf(a, b);
+    const float sec_lo = lo3(fmaxf(a, b), am, bm);       // second smallest of l0 .. l5
+    const float dmin = fminf(lo3(d0, d1, d2), fminf(d3, d4));
+    sec = fminf(sec_lo, dmin);
+    (void)big;
+}
+
+struct BfPend {
+    float v0, v1;      // pending keys (tagged bounds)
+    uint32_t r0, r1;   // their rows
+    uint32_t c;        // slots in use
+};
+__device__ __forceinline__ void bf_capture(BfPend &pd, float mn, float tau, uint32_t rowb) {
+    const bool hit = mn < tau;
+    const uint32_t t = __float_as_uint(mn) & 15u;
+    const uint32_t row = rowb + (t & 3u) + 8u * (t >> 2);  // C/D map of the 32x32 MFMA (rowb includes 4 h)
+    const bool s0 = hit && pd.c == 0u, s1 = hit && pd.c != 0u;
+    pd.v0 = s0 ? mn : pd.v0;
+    pd.r0 = s0 ? row : pd.r0;
+    pd.v1 = s1 ? mn : pd.v1;
+    pd.r1 = s1 ? row : pd.r1;
+    pd.c += hit ? 1u : 0u;
+}
+// EMB (main pass): in the shadow the VALU also (1) writes each bound's register number into its low four mantissa bits
+// (one v_and_or_b32), so that the minimum names its row, and (2) compares every bound with the query's threshold; the
+// scalar unit folds the sixteen lane masks into `dup` = lanes that hold MORE THAN ONE bound below the threshold.  With
+// dup == 0 (all but one check in a few thousand) a lane's only survivor is its minimum, and the caller captures it
+// without a branch (bf_capture).  The tagged values differ from the bounds by less than 2^-19 relative, which the
+// proof in select.hip subtracts.
+template <int KS, bool CI, bool EMB>
 __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
                                          const bf16x8 (&b1)[KS], const f32x16 &c0, f32x16 &w0, f32x16 &w1, f32x16 &r0,
-                                         f32x16 &r1, float &m0, float &m1) {
+                                         f32x16 &r1, float &m0, float &m1, float tau0, float tau1,
+                                         unsigned long long &dup0, unsigned long long &dup1, BfPend &pd0, BfPend &pd1,
+                                         float cap0, float cap1, uint32_t cap_rowb) {
     bf16x8 f[KS];
 #pragma unroll
     for (int i = 0; i < kLA && i < KS; ++i) f[i] = pre[i];
@@ -435,24 +484,47 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
             w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : z, 0, 0, 0);
             w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : z, 0, 0, 0);
         }
+        if (EMB && ks == 1) {
+            // the survivors of the block filtered BEFORE this chain (its minima cap0 / cap1, +inf where the general path
+            // has dealt with it) go to their pending slots here, in the matrix pipe's shadow: whatever a wave does
+            // between two chains is on its critical path, whatever it does inside one is not
+            bf_capture(pd0, cap0, tau0, cap_rowb);
+            bf_capture(pd1, cap1, tau1, cap_rowb);
+        }
 #ifdef PN_DIAG_BF_NOSCAN  // timing-only: no minimum
         if (ks == 0) {
             m0 = __uint_as_float(0x7F800000u);
             m1 = m0;
+            dup0 = dup1 = 0ull;
             asm volatile("" ::"v"(r0[0]), "v"(r1[0]));
         }
         if (false) {
 #else
         if (ks == 0) {
 #endif
-            float x = r0[0], y = r1[0];
+            if (EMB) {
 #pragma unroll
-            for (int i = 1; i < 16; ++i) {
-                x = fminf(x, r0[i]);
-                y = fminf(y, r1[i]);
+                for (int i = 0; i < 16; ++i) {
+                    r0[i] = __uint_as_float((__float_as_uint(r0[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                    r1[i] = __uint_as_float((__float_as_uint(r1[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                }
+                // smallest AND second smallest of the 16 bounds by triples (v_min3 / v_med3): a lane holds two bounds
+                // below its threshold exactly when its second smallest is -- no per-register compares, no scalar work
+                float s0, s1;
+                bf_min2(r0, m0, s0);
+                bf_min2(r1, m1, s1);
+                dup0 = __ballot(s0 < tau0);
+                dup1 = __ballot(s1 < tau1);
+            } else {
+                float x = r0[0], y = r1[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    x = fminf(x, r0[i]);
+                    y = fminf(y, r1[i]);
+                }
+                m0 = x;
+                m1 = y;
             }
-            m0 = x;
-            m1 = y;
         }
     }
 }
@@ -562,6 +634,60 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t 
 #endif
 }
 
+// Survivors wait in registers: per lane and query block two pending (key, row) slots.  bf_capture is straight-line code
+// -- a compare, the row number from the minimum's tag, four selects -- so a check that finds a survivor costs what a
+// check that finds none costs, and the waves of a workgroup stay in step (with the append behind a branch, ~20 % of the
+// checks entered it, each entry delayed its wave by a few hundred cycles, and the tile barrier made the other three
+// waves wait for it: measured 0.66 of 2.8 ms on C2).  bf_flush appends the pending entries of one query block; the
+// caller runs it when some lane has both slots in use (every ~20 tiles) and at the end of the run.
+template <int M, bool RAD>
+__device__ __forceinline__ void bf_flush(BfPend &pd, float &tau, uint32_t &cnt, int h, int jq, int lane, uint32_t kp,
+                                         uint2 *ceq, uint2 *ce_blk, uint32_t &ns BF_DBG_ARG) {
+    constexpr uint32_t CAP = 64u * M;
+    BF_COUNT(0, 1);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const bool p = pd.c > (uint32_t)sl;
+        if (__any(p)) {
+            const uint32_t pp = p ? 1u : 0u;
+            const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
+            const uint32_t other = h ? sw[0] : sw[1];  // the other half's lane of the same query
+            const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
+            // (o >= CAP only for a radius buffer that has already overflowed: count CAP + 1, nothing is kept)
+            if (p && o < CAP) ceq[o] = make_uint2(f2s(sl ? pd.v1 : pd.v0), sl ? pd.r1 : pd.r0);
+            BF_COUNT(1, __popcll(__ballot(p)));
+            cnt += pp + other;
+            ns += 1;
+        }
+    }
+    pd.c = 0u;
+    if (RAD) {
+        if (cnt > CAP - 32) {  // would need compacting: overflow, and nothing more is stored
+            cnt = CAP + 1;
+            tau = __uint_as_float(0xFF800000u);
+        }
+        return;
+    }
+    unsigned long long need = __ballot(h == 0 && cnt > CAP - 32);
+    if (need) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the entries must have left before they are read back
+        ns = 0;
+        do {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+            uint32_t T, nn;
+            BF_COUNT(2, 1);
+            bf_compact<M>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
+            if (jq == j) {
+                tau = s2f(T);
+                cnt = nn;
+            }
+        } while (need);
+        ns += 16;  // at least: forces the plain wait at the next barrier
+    }
+}
+
 // Wait until this wave's LDS-DMA of the next tile has landed WITHOUT waiting for the (younger) candidate
 // stores: vector-memory operations of a wave retire in order, so "at most ns outstanding" is enough when ns
 // store instructions were issued after the DMA.  s_waitcnt takes an immediate: 16 cases, larger counts wait
@@ -588,7 +714,10 @@ __device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
 }
 
 // cand: [nseg][nq_pad][64*M] (key, row) pairs; ccnt/ctau: [nseg][nq_pad], pre-initialised to 0 / sortable(+inf)
-template <int KS, int M, bool RAD, bool CI>
+// MODE 0: a run may scout for itself, then filters (plans without a shared scout); 1: scout-only launch (scout_out
+// given, no buffers touched); 2: filter with the thresholds in tau_init (no scout code: the scout pass's lists and
+// accumulators would otherwise set the kernel's register count, and main-loop values would live in scratch).
+template <int KS, int M, bool RAD, bool CI, int MODE, bool CAPT>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
                                                              uint32_t kp, uint2 *__restrict__ cand,
@@ -692,17 +821,17 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         uint32_t t_scout = run_len / 16u < 64u ? run_len / 16u : 64u;
         if (t_scout > scout_max) t_scout = scout_max;  // host: keeps the scouted rows' share of true neighbours tiny
         if (t_scout < 4u) t_scout = 0;
-        if (tau_init) {  // thresholds given by the caller (radius queries): no scouting
+        if (MODE == 2 || tau_init) {  // thresholds given by the caller (radius queries, shared seed): no scouting
             t_scout = 0;
             tau0 = s2f(tau_init[q0 + jq]);
             tau1 = s2f(tau_init[q0 + 32 + jq]);
         }
 #endif
-        if (scout_out) {  // scout-only launch: every run contributes its lists, however short it is
+        if (MODE == 1 || (MODE == 0 && scout_out)) {  // scout-only launch: every run contributes its lists
             t_scout = run_len < scout_max ? run_len : scout_max;
             if (t_scout < 1u) t_scout = 1u;
         }
-        if (t_scout) {
+        if (MODE != 2 && t_scout) {
             const float inf = __uint_as_float(0x7F800000u);
             float s0[kScoutList], s1[kScoutList];
 #pragma unroll
@@ -740,10 +869,14 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 }
                 if (rt + 1 < rt0 + t_scout) dma_tile(rt + 1, cs ^ 1);
                 float m0, m1;
-                bf_chain<KS, CI>(arow0, pre0, b0, b1, c0, x00, x01, x10, x11, m0, m1);
+                unsigned long long du0, du1;
+                BfPend dp_{0.0f, 0.0f, 0u, 0u, 0u};
+                bf_chain<KS, CI, false>(arow0, pre0, b0, b1, c0, x00, x01, x10, x11, m0, m1, 0.0f, 0.0f, du0, du1, dp_, dp_,
+                                        0.0f, 0.0f, 0u);
                 insert(s0, m0);
                 insert(s1, m1);
-                bf_chain<KS, CI>(arow1, pre1, b0, b1, c1, x10, x11, x00, x01, m0, m1);
+                bf_chain<KS, CI, false>(arow1, pre1, b0, b1, c1, x10, x11, x00, x01, m0, m1, 0.0f, 0.0f, du0, du1, dp_, dp_,
+                                        0.0f, 0.0f, 0u);
                 insert(s0, m0);
                 insert(s1, m1);
                 __syncthreads();
@@ -756,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             }
             insert(s0, m0);
             insert(s1, m1);
-            if (scout_out) {
+            if (MODE == 1 || (MODE == 0 && scout_out)) {
                 // publish this lane's lists: [cell][half][kScoutList]; bf16_seed_kernel merges the cells of a query
                 float *o0 = scout_out + ((cell0 + jq) * 2 + h) * kScoutList;
                 float *o1 = scout_out + ((cell0 + 32 + jq) * 2 + h) * kScoutList;
@@ -779,6 +912,10 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             tau0 = union5(s0);
             tau1 = union5(s1);
         }
+        if (MODE == 1) {  // (a scout-only run always left through the `continue` above)
+            u0 = run_end;
+            continue;
+        }
         uint2 *ce_blk0 = cand + cell0 * CAP;              // query block 0: 32 buffers
         uint2 *ce_blk1 = ce_blk0 + (size_t)32 * CAP;      // query block 1
         uint2 *ceq0 = ce_blk0 + (size_t)jq * CAP, *ceq1 = ce_blk1 + (size_t)jq * CAP;
@@ -789,6 +926,15 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         dma_tile(rt0, 0);
         __syncthreads();  // carries the vmcnt(0)
 
+        // Two ways to deal with the survivors of a (32-row block, query block) check, chosen by the host per plan:
+        //  * CAPT = false (small k': a check finds a survivor in ~20 % of the cases): a branch into bf_slow, which finds
+        //    the survivors' registers by compare and appends them at once;
+        //  * CAPT = true (larger k': survivors are frequent): branch-free capture into two pending register slots per
+        //    lane inside the next chain's shadow (bf_capture), appended in batches (bf_flush).  It costs ~80 vector
+        //    instructions more per chain whether anything survives or not -- measured on one device, 1M rows: k = 10
+        //    2.79 (branch) vs 3.14 ms (capture) at D = 128, 2.10 vs 2.24 at D = 64; k = 100 4.50 vs 4.20 at D = 128,
+        //    3.98 vs 3.18 at D = 64.
+        if (!CAPT) {
         // Pipeline per tile rt (two 32-row blocks, accumulators a0x / a1x for the two query blocks x):
         //   [barrier passed: tile rt is in LDS]  first fragments of both blocks requested; DMA of tile rt+1
         //   rare path for block 0 of tile rt-1 (minima taken during the previous chain)
@@ -803,6 +949,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             a11[r] = 3.0e38f;
         }
         float p0 = __uint_as_float(0x7F800000u), p1 = p0;  // minima of a00 / a01 still to be filtered
+        unsigned long long du0_, du1_;
+        BfPend pdx_{0.0f, 0.0f, 0u, 0u, 0u};
         int cur = 0;
         for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1) {
             const char *tb = tiles + cur * TB;
@@ -827,14 +975,14 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
             float m0, m1;
-            bf_chain<KS, CI>(arow0, pre0, b0, b1, c0, a00, a01, a10, a11, m0, m1);
+            bf_chain<KS, CI, false>(arow0, pre0, b0, b1, c0, a00, a01, a10, a11, m0, m1, 0.0f, 0.0f, du0_, du1_, pdx_, pdx_, 0.0f, 0.0f, 0u);
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
                 if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
                 if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
-            bf_chain<KS, CI>(arow1, pre1, b0, b1, c1, a10, a11, a00, a01, p0, p1);
+            bf_chain<KS, CI, false>(arow1, pre1, b0, b1, c1, a10, a11, a00, a01, p0, p1, 0.0f, 0.0f, du0_, du1_, pdx_, pdx_, 0.0f, 0.0f, 0u);
             // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
 #if defined(PN_DIAG_BF_COUNT)
             const unsigned long long tb0_ = bf_stamp();
@@ -864,6 +1012,130 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             row0 += 32;
             if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
             if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+        }
+        } else {
+        // Pipeline per tile rt (two 32-row blocks, accumulators a0x / a1x for the two query blocks x):
+        //   [barrier passed: tile rt is in LDS]  first fragments of both blocks requested; DMA of tile rt+1
+        //   rare path for block 0 of tile rt-1 (minima taken during the previous chain)
+        //   chain(block 0) -> a0x while the VALU takes the minima of a1x (block 1 of tile rt-1); its rare path
+        //   chain(block 1) -> a1x while the VALU takes the minima of a0x; barrier
+        f32x16 a00, a01, a10, a11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // "nothing here yet": above every threshold
+            a00[r] = 3.0e38f;
+            a01[r] = 3.0e38f;
+            a10[r] = 3.0e38f;
+            a11[r] = 3.0e38f;
+        }
+        float p0 = __uint_as_float(0x7F800000u), p1 = p0;  // (tagged) minima of a00 / a01 still to be filtered
+        unsigned long long dp0 = 0ull, dp1 = 0ull;         // lanes with more than one survivor in a00 / a01
+        BfPend pd0{0.0f, 0.0f, 0u, 0u, 0u}, pd1{0.0f, 0.0f, 0u, 0u, 0u};
+        // one (block, query block) result: the general path when some lane holds several survivors (rare), else the
+        // branch-free capture; then a flush when some lane has both pending slots in use
+#define PN_BF_DUPS(ACC0, ACC1, MN0, MN1, DUP0, DUP1, ROW0)                                                               \
+    do { /* some lane holds several survivors (rare): general path now, the capture in the next chain then skips it */  \
+        if ((DUP0) | (DUP1)) {                                                                                            \
+            if (DUP0) {                                                                                                   \
+                bf_slow<M, RAD>(ACC0, tau0, cnt0, (ROW0), h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);               \
+                MN0 = __uint_as_float(0x7F800000u);                                                                       \
+            }                                                                                                             \
+            if (DUP1) {                                                                                                   \
+                bf_slow<M, RAD>(ACC1, tau1, cnt1, (ROW0), h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);               \
+                MN1 = __uint_as_float(0x7F800000u);                                                                       \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+#define PN_BF_FLUSH_IF_FULL()                                                                                             \
+    do {                                                                                                                  \
+        if (__any(pd0.c > 1u || pd1.c > 1u)) {                                                                            \
+            bf_flush<M, RAD>(pd0, tau0, cnt0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);                            \
+            bf_flush<M, RAD>(pd1, tau1, cnt1, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);                            \
+        }                                                                                                                 \
+    } while (0)
+        int cur = 0;
+        for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1) {
+            const char *tb = tiles + cur * TB;
+            const char *arow0 = tb + (jq * CP + h) * 16;
+            const char *arow1 = arow0 + 32 * CP * 16;
+            bf16x8 pre0[kLA];
+#pragma unroll
+            for (int i = 0; i < kLA; ++i) pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
+            f32x16 c0 = a00;  // (placeholder unless CI)
+            if (CI) c0 = bf_cinit<CP>(tb, 0, h);
+            if (rt + 1 < rt1) dma_tile(rt + 1, cur ^ 1);
+            ns = 0;
+            // block 0 of tile rt-1 (scanned in the shadow of that tile's second chain): captured inside the first chain
+            PN_BF_DUPS(a00, a01, p0, p1, dp0, dp1, (rt - 1) * kBP);
+            PN_BF_FLUSH_IF_FULL();
+            float m0, m1;
+            unsigned long long dm0, dm1;
+            bf_chain<KS, CI, true>(arow0, pre0, b0, b1, c0, a00, a01, a10, a11, m0, m1, tau0, tau1, dm0, dm1, pd0, pd1, p0, p1,
+                                   (rt - 1) * kBP + 4u * (uint32_t)h);
+            if (rt == rt0) {  // nothing precedes the first tile
+                m0 = __uint_as_float(0x7F800000u);
+                m1 = m0;
+                dm0 = dm1 = 0ull;
+            }
+            // the second block's first fragments (and norms) are requested only now: their registers are not live
+            // across the first chain, and the filter step below covers the LDS latency
+            bf16x8 pre1[kLA];
+#pragma unroll
+            for (int i = 0; i < kLA; ++i) pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
+            f32x16 c1 = a10;  // (placeholder unless CI)
+            if (CI) c1 = bf_cinit<CP>(tb, 1, h);
+            // block 1 of tile rt-1 (scanned in the shadow of the chain just issued): captured inside the second chain
+            PN_BF_DUPS(a10, a11, m0, m1, dm0, dm1, (rt - 1) * kBP + 32);
+            PN_BF_FLUSH_IF_FULL();
+            bf_chain<KS, CI, true>(arow1, pre1, b0, b1, c1, a10, a11, a00, a01, p0, p1, tau0, tau1, dp0, dp1, pd0, pd1, m0, m1,
+                                   (rt - 1) * kBP + 32u + 4u * (uint32_t)h);
+            // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
+#if defined(PN_DIAG_BF_COUNT)
+            const unsigned long long tb0_ = bf_stamp();
+#endif
+#if !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
+            bf_wait_dma(ns);
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PN_DIAG_BF_NOBARRIER  // NOBARRIER is timing-only
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+#if defined(PN_DIAG_BF_COUNT)
+            BF_COUNT(6, bf_stamp() - tb0_);
+#endif
+        }
+        {  // drain: both blocks of the last tile, then whatever is still pending
+            unsigned long long dm0 = 0ull, dm1 = 0ull, sn0 = 0ull, sn1 = 0ull;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                a10[i] = __uint_as_float((__float_as_uint(a10[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                a11[i] = __uint_as_float((__float_as_uint(a11[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                const unsigned long long k0 = __ballot(a10[i] < tau0), k1 = __ballot(a11[i] < tau1);
+                dm0 |= sn0 & k0;
+                sn0 |= k0;
+                dm1 |= sn1 & k1;
+                sn1 |= k1;
+            }
+            float m0 = a10[0], m1 = a11[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                m0 = fminf(m0, a10[i]);
+                m1 = fminf(m1, a11[i]);
+            }
+            PN_BF_DUPS(a00, a01, p0, p1, dp0, dp1, (rt1 - 1) * kBP);
+            PN_BF_FLUSH_IF_FULL();
+            bf_capture(pd0, p0, tau0, (rt1 - 1) * kBP + 4u * (uint32_t)h);
+            bf_capture(pd1, p1, tau1, (rt1 - 1) * kBP + 4u * (uint32_t)h);
+            // (a threshold lowered meanwhile only makes dm0 / dm1 conservative)
+            PN_BF_DUPS(a10, a11, m0, m1, dm0, dm1, (rt1 - 1) * kBP + 32);
+            PN_BF_FLUSH_IF_FULL();
+            bf_capture(pd0, m0, tau0, (rt1 - 1) * kBP + 32u + 4u * (uint32_t)h);
+            bf_capture(pd1, m1, tau1, (rt1 - 1) * kBP + 32u + 4u * (uint32_t)h);
+            bf_flush<M, RAD>(pd0, tau0, cnt0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+            bf_flush<M, RAD>(pd1, tau1, cnt1, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+        }
+#undef PN_BF_DUPS
+#undef PN_BF_FLUSH_IF_FULL
         }
         // ---- end of run: at most kp candidates per query stay; publish count and threshold
         {
@@ -1310,20 +1582,40 @@ hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, 
     return hipGetLastError();
 }
 
+// The branch-free capture path (CAPT, see the kernel) is measured, parity-tested and NOT used by default: it wins where
+// survivors are frequent and the kernel is launched with thresholds (1M x 128, k = 100: 4.50 -> 4.20 ms) but needs ~25
+// registers more than the 256 a wave has at two workgroups per CU, and the spills cost more than it saves on the plans
+// that scout for themselves (configs[2] at full size: 250 -> 335 ms).  -DPN_DIAG_BF_CAPT turns it on for k' > 16.
+#ifdef PN_DIAG_BF_CAPT
+constexpr bool kBfCapture = true;
+#else
+constexpr bool kBfCapture = false;
+#endif
 template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, hipStream_t s) {
     const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
-    auto kern = bf16_filter_kernel<KS, M, RAD, CI>;
-    static LdsAttrOnce lds_attr;  // per instantiation
-    {
-        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
-        if (e != hipSuccess) return e;
+#define PN_BF_LAUNCH_MODE(MD)                                                                                          \
+    {                                                                                                                   \
+        auto kern = bf16_filter_kernel<KS, M, RAD, CI, MD, kBfCapture && (M > 1) && !RAD>;                                                             \
+        static LdsAttrOnce lds_attr; /* per instantiation */                                                            \
+        const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);                                 \
+        if (e != hipSuccess) return e;                                                                                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,       \
+                           static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,           \
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out);     \
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,
-                       static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,
-                       static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out);
+    if (scout_out) {
+        if (RAD) return hipErrorInvalidValue;
+        PN_BF_LAUNCH_MODE(1)
+    } else if (tau_init) {
+        PN_BF_LAUNCH_MODE(2)
+    } else {
+        if (RAD) return hipErrorInvalidValue;
+        PN_BF_LAUNCH_MODE(0)
+    }
+#undef PN_BF_LAUNCH_MODE
     return hipGetLastError();
 }
 
