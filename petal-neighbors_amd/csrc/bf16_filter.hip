@@ -60,17 +60,17 @@ typedef __attribute__((address_space(3))) void lds_void_b;
 typedef const __attribute__((address_space(1))) void glb_void_b;
 
 #ifdef PN_DIAG_BF_COUNT  // diagnostic build only: event counters
-__device__ unsigned long long g_bfdbg[8];
+__device__ unsigned long long g_bfdbg[12];
 // per-wave accumulators in registers (dbg_), flushed by one atomic per counter at the end of a run: an atomic per
 // event would itself be what the barrier waits for
 #define BF_COUNT(i, v) (dbg_[i] += (unsigned long long)(v))
-#define BF_DBG_DECL unsigned long long dbg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define BF_DBG_ARG , unsigned long long (&dbg_)[8]
+#define BF_DBG_DECL unsigned long long dbg_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define BF_DBG_ARG , unsigned long long (&dbg_)[12]
 #define BF_DBG_PASS , dbg_
 #define BF_DBG_FLUSH(lane)                                                        \
     do {                                                                          \
         if ((lane) == 0)                                                          \
-            for (int i_ = 0; i_ < 8; ++i_) {                                      \
+            for (int i_ = 0; i_ < 12; ++i_) {                                     \
                 atomicAdd(&g_bfdbg[i_], dbg_[i_]);                                \
                 dbg_[i_] = 0;                                                     \
             }                                                                     \
@@ -80,6 +80,13 @@ __device__ __forceinline__ unsigned long long bf_stamp() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+// a stamp that does not wait for itself (the wait would also wait for the fragment reads in flight): settle it before use
+__device__ __forceinline__ unsigned long long bf_stamp_nw() {
+    unsigned long long t;
+    asm volatile("s_memtime %0" : "=s"(t));
+    return t;
+}
+__device__ __forceinline__ void bf_settle(unsigned long long &t) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t)::"memory"); }
 #else
 #define BF_COUNT(i, v) ((void)0)
 #define BF_DBG_DECL ((void)0)
@@ -515,17 +522,23 @@ __device__ __forceinline__ void bf_chain(const char *arow, const bf16x8 (&pre)[k
                 bf_min2(r1, m1, s1);
                 dup0 = __ballot(s0 < tau0);
                 dup1 = __ballot(s1 < tau1);
-            } else {
-                float x = r0[0], y = r1[0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) {
-                    x = fminf(x, r0[i]);
-                    y = fminf(y, r1[i]);
-                }
-                m0 = x;
-                m1 = y;
             }
         }
+#ifndef PN_DIAG_BF_NOSCAN
+        if (!EMB) {  // this step's share of the other block's minimum: registers [16 ks / KS, 16 (ks + 1) / KS)
+#pragma unroll
+            for (int i = 16 * ks / KS; i < 16 * (ks + 1) / KS; ++i) {
+                m0 = i ? fminf(m0, r0[i]) : r0[0];
+                m1 = i ? fminf(m1, r1[i]) : r1[0];
+            }
+        }
+#endif
+#ifndef PN_DIAG_BF_NOSCHED
+        // One step = one fragment read (kLA steps ahead of its use), two MFMAs, a slice of the minimum -- and the
+        // scheduler keeps it that way.  Left alone it sinks the reads next to their uses to save registers (the kernel
+        // sits just under the two-waves-per-SIMD limit) and waits for them with lgkmcnt(0) in the middle of the chain.
+        if (!EMB) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
@@ -546,6 +559,71 @@ __device__ __forceinline__ f32x16 bf_cinit(const char *tb, int blk, int h) {
     return c;
 }
 
+// The chain of the software-pipelined main loop.  It starts from registers -- its first kLA fragments `pre` and its
+// accumulator init `c` were requested during the PREVIOUS chain -- and in its own last steps, where it has no
+// fragments of its own left to request, it requests the same for the NEXT chain (narow / ntb, nblk: the other block of
+// this tile, or block 0 of the next tile).  So no chain waits for LDS at its head, and whatever sits between two
+// chains (the survivor check, the barrier, the LDS-DMA issue) does not delay the first MFMA behind it by a round trip.
+template <int KS, bool CI, int CP>
+__device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
+                                           const bf16x8 (&b1)[KS], f32x16 &c, f32x16 &w0, f32x16 &w1, const f32x16 &r0,
+                                           const f32x16 &r1, float &m0, float &m1, const char *narow, const char *ntb,
+                                           int nblk, int h) {
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    bf16x8 f[KS];
+#pragma unroll
+    for (int i = 0; i < kLA && i < KS; ++i) f[i] = pre[i];
+    f32x16 z, nc = c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+#ifdef PN_DIAG_BF_NOSCAN  // timing-only: no minimum
+    m0 = __uint_as_float(0x7F800000u);
+    m1 = m0;
+    asm volatile("" ::"v"(r0[0]), "v"(r1[0]));
+#endif
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + kLA < KS) f[ks + kLA] = *reinterpret_cast<const bf16x8 *>(arow + 32 * (ks + kLA));
+        // the next chain's first fragments: fragment i at step max(0, KS - kLA + i)
+#pragma unroll
+        for (int i = 0; i < kLA; ++i)
+            if (ks == (KS - kLA + i > 0 ? KS - kLA + i : 0))
+                pre[i] = *reinterpret_cast<const bf16x8 *>(narow + 32 * (i < KS ? i : 0));
+        if (CI) {  // ... and its accumulator init: piece g at step max(0, KS - 4 + g)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (ks == (KS - 4 + g > 0 ? KS - 4 + g : 0)) {
+                    const f32x4_ v =
+                        *reinterpret_cast<const f32x4_ *>(ntb + ((nblk * 8 + 2 * g + h) * CP + (CP - 1)) * 16);
+                    nc[4 * g + 0] = v[0];
+                    nc[4 * g + 1] = v[1];
+                    nc[4 * g + 2] = v[2];
+                    nc[4 * g + 3] = v[3];
+                }
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : c, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : c, 0, 0, 0);
+#ifndef PN_DIAG_BF_NOKEEPC
+            // c outlives both MFMAs that read it: otherwise the second one accumulates IN c's registers, its proper
+            // registers serve as fragment space meanwhile, and sixteen moves that wait for the matrix pipe bring the
+            // result home before the last step
+            if (ks == 0) asm volatile("" ::"v"(c));
+#endif
+        } else {
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : z, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : z, 0, 0, 0);
+        }
+#ifndef PN_DIAG_BF_NOSCAN
+#pragma unroll
+        for (int i = 16 * ks / KS; i < 16 * (ks + 1) / KS; ++i) {  // this step's share of the other block's minimum
+            m0 = i ? fminf(m0, r0[i]) : r0[0];
+            m1 = i ? fminf(m1, r1[i]) : r1[0];
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);  // a step stays a step (see bf_chain)
+    }
+    c = nc;
+}
+
 // append this lane's survivors of one (32-row block, query block) and compact the buffers that filled up.
 // cnt is the fill count of the lane's query (identical in lanes j and j+32, which hold different rows).
 // ns counts the vector-memory instructions this wave has issued since its last LDS-DMA (wave-uniform): the
@@ -558,8 +636,9 @@ __device__ __forceinline__ f32x16 bf_cinit(const char *tb, int blk, int h) {
 // a buffer that would need compacting is marked overflowed instead (count > capacity; the host re-runs the call
 // on the exact engine) and its threshold drops to -inf so that nothing more is stored.
 template <int M, bool RAD>
-__device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t &cnt, uint32_t row0, int h, int jq,
-                                        int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk, uint32_t &ns BF_DBG_ARG) {
+__device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
+                                        int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk,
+                                        uint32_t &ns BF_DBG_ARG) {
 #ifdef PN_DIAG_BF_NOSLOW  // timing-only build: results are wrong
     asm volatile("" ::"v"(acc[0]), "v"(tau));
 #ifdef PN_DIAG_BF_FAKESLOW
@@ -575,9 +654,44 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t 
 #endif
     float t = tau;
     asm volatile("" : "+v"(t));  // opaque from here on: nothing below can be speculated above the caller's branch
+    // The siblings of this wave meet it at the next tile barrier, so its detour is the workgroup's: it outranks the
+    // SIMD's other wave (another workgroup, in its chain) for vector issue while it lasts.  Measured on one device:
+    // C2 -1 %, 1M x 128 k = 100 -2.5 %; raising the priority of the whole stretch between two chains instead: no gain.
+    __builtin_amdgcn_s_setprio(1);
     const uint32_t rowb = row0 + 4 * h;
-    // (measured alternative: all sixteen compares first, then a scalar loop over the registers with survivors and a
-    // switch to read them -- 1320 instead of 1130 cycles per entry, C2 2.91 instead of 2.78 ms)
+    // Which registers survive.  Nearly always (C2: 99.7 % of the entries) no lane has more than one -- then the lane's
+    // survivor IS its block minimum mn, already known -- so the search is straight-line: sixteen compares whose lane
+    // masks are folded on the scalar unit into "some lane has two" (dup) and, per lane, the index of the register that
+    // passed.  One store instruction then appends for every surviving lane at once.  (The version before this one
+    // branched per register -- sixteen vector-compare -> scalar-branch round trips, 1130 cycles per entry at ~0.4
+    // entries per tile and wave; measured alternative to that: all compares first, then a scalar loop over the
+    // registers with survivors and a switch to read them, 1320 cycles.)
+#ifndef PN_DIAG_BF_SLOW_LOOP
+    unsigned long long seen = 0ull, dup = 0ull;
+    uint32_t ridx = 16u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool p = acc[r] < t;
+        const unsigned long long m = __ballot(p);
+        dup |= seen & m;
+        seen |= m;
+        ridx = p ? (uint32_t)r : ridx;
+    }
+    if (dup == 0ull) {
+        const bool p = ridx < 16u;
+        const uint32_t pp = p ? 1u : 0u;
+        const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
+        const uint32_t other = h ? sw[0] : sw[1];  // the other half's lane of the same query
+        if (p) {
+            const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
+            // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
+            ceq[o] = make_uint2(f2s(mn), rowb + (ridx & 3u) + 8u * (ridx >> 2));
+        }
+        BF_COUNT(1, __popcll(seen));
+        cnt += pp + other;
+        ns += 1;
+    } else
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
@@ -601,6 +715,7 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t 
             cnt = CAP + 1;
             tau = __uint_as_float(0xFF800000u);
         }
+        __builtin_amdgcn_s_setprio(0);
         return;
     }
     unsigned long long need = __ballot(h == 0 && cnt > CAP - 32);
@@ -625,6 +740,7 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float &tau, uint32_t 
         } while (need);
         ns += 16;  // at least: forces the plain wait at the next barrier
     }
+    __builtin_amdgcn_s_setprio(0);
 #ifdef PN_DIAG_BF_COUNT
     {
         const unsigned long long t3_ = bf_stamp();
@@ -731,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     constexpr uint32_t CAP = 64u * M;
     constexpr int TB = kBP * CP * 16;  // bytes per tile image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    char *tiles = reinterpret_cast<char *>(smem_raw);  // [2][TB]
+    char *tiles = reinterpret_cast<char *>(smem_raw);  // [3][TB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -744,7 +860,24 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     // [w U / W, (w+1) U / W) and walks it in runs that stay inside one (query tile, part).
     const uint32_t tps = (n_tiles + split - 1) / split;
     const unsigned long long U = (unsigned long long)q_tiles * split * tps;
-    const unsigned long long W = gridDim.x, w = blockIdx.x;
+    const unsigned long long W = gridDim.x;
+    unsigned long long w = blockIdx.x;
+#ifndef PN_DIAG_BF_NOREMAP
+    // Which slice a hardware block takes (aligned grids: c = W / q_tiles whole workgroups per query tile, slice
+    // q c + p = row range p of query tile q).  Hardware block b runs on XCD b % 8 and every XCD has its own L2, so
+    // the blocks of one XCD take a contiguous range of the RANGE-MAJOR order (p, q): the workgroups resident on an
+    // XCD at any time -- 2 per CU, started together or as their predecessors finish together -- are different query
+    // tiles walking the SAME row range, and a tile image one of them brought into L2 serves the others.  In
+    // query-major order the residents of an XCD walk c different ranges, and in a grid that runs in rounds a
+    // finished workgroup's successor starts a range from its beginning, alone (10M x 128, 10^5 queries: L2 hit
+    // rate 9 %, 0.98 TB from HBM per step, 3.9 TB/s).
+    if (split == 1 && W >= q_tiles && W % q_tiles == 0) {
+        const uint32_t b = blockIdx.x, x = b & 7u, base = (uint32_t)W >> 3, rem = (uint32_t)W & 7u;
+        const uint32_t L = x * base + (x < rem ? x : rem) + (b >> 3);  // XCDs 0 .. rem-1 run base + 1 blocks
+        const uint32_t c = (uint32_t)W / q_tiles;
+        w = (unsigned long long)(L % q_tiles) * c + L / q_tiles;
+    }
+#endif
     unsigned long long u0 = w * U / W;
     const unsigned long long u1 = (w + 1) * U / W;
 
@@ -921,11 +1054,6 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         uint2 *ceq0 = ce_blk0 + (size_t)jq * CAP, *ceq1 = ce_blk1 + (size_t)jq * CAP;
         uint32_t ns = 0;
 
-        // ---- prologue: first tile -> LDS[0]
-        __syncthreads();  // previous run's readers are done with both buffers
-        dma_tile(rt0, 0);
-        __syncthreads();  // carries the vmcnt(0)
-
         // Two ways to deal with the survivors of a (32-row block, query block) check, chosen by the host per plan:
         //  * CAPT = false (small k': a check finds a survivor in ~20 % of the cases): a branch into bf_slow, which finds
         //    the survivors' registers by compare and appends them at once;
@@ -935,11 +1063,22 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         //    2.79 (branch) vs 3.14 ms (capture) at D = 128, 2.10 vs 2.24 at D = 64; k = 100 4.50 vs 4.20 at D = 128,
         //    3.98 vs 3.18 at D = 64.
         if (!CAPT) {
-        // Pipeline per tile rt (two 32-row blocks, accumulators a0x / a1x for the two query blocks x):
-        //   [barrier passed: tile rt is in LDS]  first fragments of both blocks requested; DMA of tile rt+1
-        //   rare path for block 0 of tile rt-1 (minima taken during the previous chain)
-        //   chain(block 0) -> a0x while the VALU takes the minima of a1x (block 1 of tile rt-1); its rare path
-        //   chain(block 1) -> a1x while the VALU takes the minima of a0x; barrier
+        // Software pipeline over the tiles of the run, three LDS buffers (tile rt in buffer (rt - rt0) % 3):
+        //   chain A: block 0 of tile rt -> a0x, the VALU takes the minima of a1x (block 1 of tile rt-1) in its shadow;
+        //            its last steps request block 1's first fragments and accumulator init
+        //   survivors of a1x (rare path)
+        //   barrier -- in the MIDDLE of the tile: every wave's pieces of tile rt+1 have landed (they were issued a whole
+        //            tile ago, so the wait is over before it starts) and nobody reads tile rt-1 any more; LDS-DMA of
+        //            tile rt+2 into that buffer.  What follows the barrier needs nothing the barrier provides:
+        //   chain B: block 1 of tile rt -> a1x, minima of a0x; its last steps request block 0 of tile rt+1
+        //   survivors of a0x (rare path)
+        // With two buffers and the barrier at the end of a tile (round 1) every tile began cold behind the barrier:
+        // fragment and norm reads, their round trip, the DMA issue -- a quarter of a wave's time with no MFMA in it
+        // (measured with per-section stamps, rare path compiled out: 628 of 2 630 cycles per tile).
+        __syncthreads();  // previous run's readers are done with the buffers
+        dma_tile(rt0, 0);
+        if (rt0 + 1 < rt1) dma_tile(rt0 + 1, 1);
+        __syncthreads();  // carries the vmcnt(0): tiles rt0 and rt0 + 1 are in LDS
         f32x16 a00, a01, a10, a11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // "nothing here yet": above every threshold
@@ -948,42 +1087,41 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             a10[r] = 3.0e38f;
             a11[r] = 3.0e38f;
         }
-        float p0 = __uint_as_float(0x7F800000u), p1 = p0;  // minima of a00 / a01 still to be filtered
-        unsigned long long du0_, du1_;
-        BfPend pdx_{0.0f, 0.0f, 0u, 0u, 0u};
+        bf16x8 pre[kLA];
+        f32x16 cc = a00;  // (placeholder unless CI)
+        {
+            const char *ar = tiles + (jq * CP + h) * 16;
+#pragma unroll
+            for (int i = 0; i < kLA; ++i) pre[i] = *reinterpret_cast<const bf16x8 *>(ar + 32 * (i < KS ? i : 0));
+            if (CI) cc = bf_cinit<CP>(tiles, 0, h);
+        }
+        ns = 0;
         int cur = 0;
-        for (uint32_t rt = rt0; rt < rt1; ++rt, cur ^= 1) {
+        for (uint32_t rt = rt0; rt < rt1; ++rt) {
+            const int nxt = cur == 2 ? 0 : cur + 1, prv = cur == 0 ? 2 : cur - 1;
             const char *tb = tiles + cur * TB;
             const char *arow0 = tb + (jq * CP + h) * 16;
             const char *arow1 = arow0 + 32 * CP * 16;
-            bf16x8 pre0[kLA], pre1[kLA];
-#pragma unroll
-            for (int i = 0; i < kLA; ++i) {
-                pre0[i] = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * (i < KS ? i : 0));
-                pre1[i] = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * (i < KS ? i : 0));
+            float m0, m1, p0, p1;
+#if defined(PN_DIAG_BF_COUNT)
+            unsigned long long tc0_ = bf_stamp_nw();
+#endif
+            bf_chain_p<KS, CI, CP>(arow0, pre, b0, b1, cc, a00, a01, a10, a11, m0, m1, arow1, tb, 1, h);
+#if defined(PN_DIAG_BF_COUNT)
+            {
+                unsigned long long tc1_ = bf_stamp_nw();
+                bf_settle(tc1_);
+                bf_settle(tc0_);
+                BF_COUNT(9, tc1_ - tc0_);
             }
-            f32x16 c0 = a00, c1 = a00;  // (placeholders unless CI)
-            if (CI) {
-                c0 = bf_cinit<CP>(tb, 0, h);
-                c1 = bf_cinit<CP>(tb, 1, h);
-            }
-            if (rt + 1 < rt1) dma_tile(rt + 1, cur ^ 1);
-            ns = 0;
-            if (__any(p0 < tau0 || p1 < tau1)) {
-                const uint32_t row0 = (rt - 1) * kBP;
-                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
-            }
-            float m0, m1;
-            bf_chain<KS, CI, false>(arow0, pre0, b0, b1, c0, a00, a01, a10, a11, m0, m1, 0.0f, 0.0f, du0_, du1_, pdx_, pdx_, 0.0f, 0.0f, 0u);
+#endif
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
-                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
-            bf_chain<KS, CI, false>(arow1, pre1, b0, b1, c1, a10, a11, a00, a01, p0, p1, 0.0f, 0.0f, du0_, du1_, pdx_, pdx_, 0.0f, 0.0f, 0u);
-            // tile barrier: every wave's share of tile rt+1 has landed and nobody still reads tile rt
+            // mid-tile barrier
 #if defined(PN_DIAG_BF_COUNT)
             const unsigned long long tb0_ = bf_stamp();
 #endif
@@ -998,22 +1136,47 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #if defined(PN_DIAG_BF_COUNT)
             BF_COUNT(6, bf_stamp() - tb0_);
 #endif
+            if (rt + 2 < rt1) {
+                dma_tile(rt + 2, prv);
+                ns = 0;
+            }
+            const bool last = rt + 1 >= rt1;  // (then the requests below are never used: any valid LDS address)
+            const char *ntb = last ? tb : tiles + nxt * TB;
+#if defined(PN_DIAG_BF_COUNT)
+            unsigned long long tc2_ = bf_stamp_nw();
+#endif
+            bf_chain_p<KS, CI, CP>(arow1, pre, b0, b1, cc, a10, a11, a00, a01, p0, p1, ntb + (jq * CP + h) * 16, ntb, 0, h);
+#if defined(PN_DIAG_BF_COUNT)
+            {
+                unsigned long long tc3_ = bf_stamp_nw();
+                bf_settle(tc3_);
+                bf_settle(tc2_);
+                BF_COUNT(10, tc3_ - tc2_);
+            }
+#endif
+            if (__any(p0 < tau0 || p1 < tau1)) {
+                const uint32_t row0 = rt * kBP;
+                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+            }
+            cur = nxt;
         }
-        {  // drain: both blocks of the last tile
+        {  // drain: block 1 of the last tile
             float m0 = a10[0], m1 = a11[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
                 m0 = fminf(m0, a10[i]);
                 m1 = fminf(m1, a11[i]);
             }
-            uint32_t row0 = (rt1 - 1) * kBP;
-            if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-            if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
-            row0 += 32;
-            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+            const uint32_t row0 = (rt1 - 1) * kBP + 32;
+            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
         }
         } else {
+        // ---- prologue: first tile -> LDS[0]
+        __syncthreads();  // previous run's readers are done with both buffers
+        dma_tile(rt0, 0);
+        __syncthreads();  // carries the vmcnt(0)
         // Pipeline per tile rt (two 32-row blocks, accumulators a0x / a1x for the two query blocks x):
         //   [barrier passed: tile rt is in LDS]  first fragments of both blocks requested; DMA of tile rt+1
         //   rare path for block 0 of tile rt-1 (minima taken during the previous chain)
@@ -1036,11 +1199,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     do { /* some lane holds several survivors (rare): general path now, the capture in the next chain then skips it */  \
         if ((DUP0) | (DUP1)) {                                                                                            \
             if (DUP0) {                                                                                                   \
-                bf_slow<M, RAD>(ACC0, tau0, cnt0, (ROW0), h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);               \
+                bf_slow<M, RAD>(ACC0, MN0, tau0, cnt0, (ROW0), h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);               \
                 MN0 = __uint_as_float(0x7F800000u);                                                                       \
             }                                                                                                             \
             if (DUP1) {                                                                                                   \
-                bf_slow<M, RAD>(ACC1, tau1, cnt1, (ROW0), h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);               \
+                bf_slow<M, RAD>(ACC1, MN1, tau1, cnt1, (ROW0), h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);               \
                 MN1 = __uint_as_float(0x7F800000u);                                                                       \
             }                                                                                                             \
         }                                                                                                                 \
@@ -1458,9 +1621,9 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             }
             const uint32_t row0 = rt * (uint32_t)kWR + (uint32_t)(rh * 128 + rb * 32);
             if (__any(m0 < tau0))
-                bf_slow<M, RAD>(acc[rb][0], tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                bf_slow<M, RAD>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
             if (__any(m1 < tau1))
-                bf_slow<M, RAD>(acc[rb][1], tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                bf_slow<M, RAD>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
         }
     }
     // ---- end of run: at most kp candidates per query stay; publish count and threshold
@@ -1499,7 +1662,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
 
 #ifdef PN_DIAG_BF_COUNT
 extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[12] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfdbg), sizeof(z)) != hipSuccess) return 1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_bfdbg), z, sizeof(z)) != hipSuccess) return 1;
     return 0;
@@ -1595,7 +1758,7 @@ template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, hipStream_t s) {
-    const size_t sh = (size_t)2 * kBP * (2 * KS + 1) * 16;
+    const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16;  // three tile buffers (software-pipelined main loop)
 #define PN_BF_LAUNCH_MODE(MD)                                                                                          \
     {                                                                                                                   \
         auto kern = bf16_filter_kernel<KS, M, RAD, CI, MD, kBfCapture && (M > 1) && !RAD>;                                                             \

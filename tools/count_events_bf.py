@@ -15,16 +15,20 @@ t = pn.BallTree.from_device(pts)
 t.set_engine("bf16")
 if slots: t.set_option(_lib.PN_OPT_FILTER_SLOTS, slots)
 f = L.pn_debug_read_bf; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int]
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 waves = 480 * 4
-ns = lambda i: 10.0 * out[i]   # s_memtime ticks of 10 ns
-print("main launch only (the scout-only launch touches no buffers); per wave, of %d waves:" % waves)
-print("  run time            %8.3f ms" % (ns(7) / waves * 1e-6))
-print("  rare path (bf_slow) %8.3f ms in %.0f entries (%.0f ns each), %.1f appends per (segment, query) buffer" %
-      (ns(3) / waves * 1e-6, out[0] / waves, ns(3) / max(out[0], 1), out[1] / (480 * 256)))
-print("  ... of which mid-run compactions %8.3f ms in %.1f compactions (%.2f us each)" %
-      (ns(4) / waves * 1e-6, out[2] / waves, ns(4) / max(out[2], 1) * 1e-3))
-print("  end of run (final compactions + publish) %8.3f ms" % (ns(5) / waves * 1e-6))
-print("  tile barrier incl. DMA wait %8.3f ms" % (ns(6) / waves * 1e-6))
+cyc = lambda i: float(out[i])   # s_memtime ticks = shader cycles (MI355X_MICROARCH.md, constants table)
+run = cyc(7) / waves
+print("main launch only (the scout-only launch touches no buffers); means per wave, of %d waves, in shader cycles:" % waves)
+print("  run                  %10.0f cycles" % run)
+print("  rare path (bf_slow)  %10.0f cycles = %4.1f %% of the run, in %.0f entries (%.0f cycles each); %.1f appends per (segment, query) buffer" %
+      (cyc(3) / waves, 100.0 * cyc(3) / waves / run, out[0] / waves, cyc(3) / max(out[0], 1), out[1] / (480 * 256)))
+print("  ... of which mid-run compactions %10.0f cycles in %.1f compactions (%.0f cycles each)" %
+      (cyc(4) / waves, out[2] / waves, cyc(4) / max(out[2], 1)))
+print("  end of run (final compactions + publish) %10.0f cycles" % (cyc(5) / waves))
+print("  tile barrier incl. DMA wait %10.0f cycles = %4.1f %% of the run" % (cyc(6) / waves, 100.0 * cyc(6) / waves / run))
+print("  tile top to chain 1 (fragment + norm reads issued, LDS-DMA issue, check, rare path) %10.0f cycles = %4.1f %% of the run" % (cyc(8) / waves, 100.0 * cyc(8) / waves / run))
+print("  chain 1 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(9) / waves, 100.0 * cyc(9) / waves / run, cyc(9) / waves / 1302))
+print("  chain 2 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(10) / waves, 100.0 * cyc(10) / waves / run, cyc(10) / waves / 1302))

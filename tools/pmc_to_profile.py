@@ -8,7 +8,6 @@ import sys
 src, kernel, config, alg, what = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5]
 p = json.load(open(src))
 n_simd = 256 * 4
-xcd_cycles = p["GRBM_GUI_ACTIVE"] / 8.0
 out = {
     "what": what,
     "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"],
@@ -16,17 +15,22 @@ out = {
                   "(MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact",
     "hbm_bytes_per_launch": (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0,
     "algorithmic_bytes_per_launch": alg,
-    "TCC_HIT_sum": p["TCC_HIT_sum"], "TCC_MISS_sum": p["TCC_MISS_sum"],
-    "l2_hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]),
-    "GRBM_GUI_ACTIVE_sum_over_8_XCD": p["GRBM_GUI_ACTIVE"],
-    "effective_clock_GHz": xcd_cycles / (p["_kernel_ms_mean"] * 1e6),
-    "SQ_VALU_MFMA_BUSY_CYCLES": p["SQ_VALU_MFMA_BUSY_CYCLES"],
-    "mfma_pipe_busy_frac": p["SQ_VALU_MFMA_BUSY_CYCLES"] / (xcd_cycles * n_simd),
-    "SQ_INSTS_MFMA": p["SQ_INSTS_MFMA"], "SQ_INSTS_VALU_incl_MFMA": p["SQ_INSTS_VALU"],
-    "SQ_INSTS_SALU": p["SQ_INSTS_SALU"], "SQ_INSTS_VMEM_WR": p["SQ_INSTS_VMEM_WR"],
-    "valu_per_mfma": (p["SQ_INSTS_VALU"] - p["SQ_INSTS_MFMA"]) / p["SQ_INSTS_MFMA"],
-    "SQ_WAVES": p["SQ_WAVES"], "SQ_WAVE_CYCLES_quad": p["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY_quad": p["SQ_WAIT_ANY"],
-    "SQ_WAIT_INST_ANY_quad": p["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY_quad": p["SQ_ACTIVE_INST_ANY"],
     "kernel_ms_mean_under_pmc": p["_kernel_ms_mean"], "kernel": kernel, "config": config,
 }
+if "TCC_HIT_sum" in p:
+    out.update({"TCC_HIT_sum": p["TCC_HIT_sum"], "TCC_MISS_sum": p["TCC_MISS_sum"],
+                "l2_hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"])})
+if "GRBM_GUI_ACTIVE" in p:
+    xcd_cycles = p["GRBM_GUI_ACTIVE"] / 8.0
+    out.update({"GRBM_GUI_ACTIVE_sum_over_8_XCD": p["GRBM_GUI_ACTIVE"],
+                "effective_clock_GHz": xcd_cycles / (p["_kernel_ms_mean"] * 1e6),
+                "SQ_VALU_MFMA_BUSY_CYCLES": p["SQ_VALU_MFMA_BUSY_CYCLES"],
+                "mfma_pipe_busy_frac": p["SQ_VALU_MFMA_BUSY_CYCLES"] / (xcd_cycles * n_simd), "SQ_WAVES": p["SQ_WAVES"]})
+if "SQ_INSTS_MFMA" in p:
+    out.update({"SQ_INSTS_MFMA": p["SQ_INSTS_MFMA"], "SQ_INSTS_VALU_incl_MFMA": p["SQ_INSTS_VALU"],
+                "SQ_INSTS_SALU": p["SQ_INSTS_SALU"], "SQ_INSTS_VMEM_WR": p["SQ_INSTS_VMEM_WR"],
+                "valu_per_mfma": (p["SQ_INSTS_VALU"] - p["SQ_INSTS_MFMA"]) / p["SQ_INSTS_MFMA"]})
+if "SQ_WAVE_CYCLES" in p:
+    out.update({"SQ_WAVE_CYCLES_quad": p["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY_quad": p["SQ_WAIT_ANY"],
+                "SQ_WAIT_INST_ANY_quad": p["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY_quad": p["SQ_ACTIVE_INST_ANY"]})
 print(json.dumps(out, indent=1))
