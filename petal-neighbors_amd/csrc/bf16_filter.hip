@@ -425,6 +425,16 @@ constexpr int kLA = PN_DIAG_KLA;
 #else
 constexpr int kLA = 3;
 #endif
+// The main loop of the narrow kernel tags the bounds it scans (bf_chain_p) when survivors are frequent -- buffers of
+// 128 slots and more, i.e. k' > 32, and radius queries -- so that a rare-path entry finds its survivor without a search
+// (bf_slow).  The 32 tag instructions per chain are not free now that the chains are tight: measured on one device,
+// 1M rows, tags on vs off: D = 128, k = 100 3.59 vs 4.03 ms, but k = 10 2.57 vs 2.52 (D = 96: 2.23 vs 2.30, D = 64:
+// 1.94 vs 1.96 -- within a few per cent either way for 64-slot buffers, which therefore stay untagged).
+#ifdef PN_DIAG_BF_NOTAG
+constexpr int kBfTagFromM = 1000;
+#else
+constexpr int kBfTagFromM = 2;
+#endif
 constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
 // smallest (mn) and second smallest (sec) of 16 finite values: triples give (min3, med3); the second smallest overall
 // is the smaller of {second smallest of the triples' minima, the smallest of the triples' medians} -- 21 instructions.
@@ -564,10 +574,10 @@ __device__ __forceinline__ f32x16 bf_cinit(const char *tb, int blk, int h) {
 // fragments of its own left to request, it requests the same for the NEXT chain (narow / ntb, nblk: the other block of
 // this tile, or block 0 of the next tile).  So no chain waits for LDS at its head, and whatever sits between two
 // chains (the survivor check, the barrier, the LDS-DMA issue) does not delay the first MFMA behind it by a round trip.
-template <int KS, bool CI, int CP>
+template <int KS, bool CI, int CP, bool TAG>
 __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA], const bf16x8 (&b0)[KS],
-                                           const bf16x8 (&b1)[KS], f32x16 &c, f32x16 &w0, f32x16 &w1, const f32x16 &r0,
-                                           const f32x16 &r1, float &m0, float &m1, const char *narow, const char *ntb,
+                                           const bf16x8 (&b1)[KS], f32x16 &c, f32x16 &w0, f32x16 &w1, f32x16 &r0,
+                                           f32x16 &r1, float &m0, float &m1, const char *narow, const char *ntb,
                                            int nblk, int h) {
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     bf16x8 f[KS];
@@ -615,6 +625,10 @@ __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA],
 #ifndef PN_DIAG_BF_NOSCAN
 #pragma unroll
         for (int i = 16 * ks / KS; i < 16 * (ks + 1) / KS; ++i) {  // this step's share of the other block's minimum
+            if (TAG) {  // the register number goes into the low four mantissa bits first (one v_and_or_b32): see bf_slow
+                r0[i] = __uint_as_float((__float_as_uint(r0[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                r1[i] = __uint_as_float((__float_as_uint(r1[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+            }
             m0 = i ? fminf(m0, r0[i]) : r0[0];
             m1 = i ? fminf(m1, r1[i]) : r1[0];
         }
@@ -635,7 +649,7 @@ __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA],
 // RAD (radius queries): the threshold is the query's fixed radius bound and every row below it must be kept, so
 // a buffer that would need compacting is marked overflowed instead (count > capacity; the host re-runs the call
 // on the exact engine) and its threshold drops to -inf so that nothing more is stored.
-template <int M, bool RAD>
+template <int M, bool RAD, bool TAGGED = false>
 __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
                                         int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk,
                                         uint32_t &ns BF_DBG_ARG) {
@@ -669,15 +683,48 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
 #ifndef PN_DIAG_BF_SLOW_LOOP
     unsigned long long seen = 0ull, dup = 0ull;
     uint32_t ridx = 16u;
+    if (TAGGED) {
+        // The narrow kernel's main loop wrote every bound's register number into its low four mantissa bits while
+        // it took the minimum (in the matrix pipe's shadow, where vector instructions are nearly free): the minimum
+        // names its register, the sixteen values are distinct, and "some lane has two survivors" is "its second
+        // smallest passes" -- 21 instructions (bf_min2) instead of 16 compares + 47 scalar + 16 selects.  An entry is
+        // ~100 dependent instructions otherwise, and priced like a 950-cycle sleep (calibrated against timing-only
+        // builds whose entries sleep: 256 cycles +0.08 ms on C2, 512 cycles +0.24 ms, the real thing +0.52 ms).
+        float mn2, sec;
+        bf_min2(acc, mn2, sec);
+        dup = __ballot(sec < t);
+        ridx = (mn < t) ? (__float_as_uint(mn) & 15u) : 16u;
+        seen = __ballot(mn < t);
+        (void)mn2;
+    } else {
+#ifdef PN_DIAG_BF_SEARCH_MASKS  // the version before: sixteen compares, lane masks folded on the scalar unit, sixteen selects
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const bool p = acc[r] < t;
-        const unsigned long long m = __ballot(p);
-        dup |= seen & m;
-        seen |= m;
-        ridx = p ? (uint32_t)r : ridx;
+        for (int r = 0; r < 16; ++r) {
+            const bool p = acc[r] < t;
+            const unsigned long long m = __ballot(p);
+            dup |= seen & m;
+            seen |= m;
+            ridx = p ? (uint32_t)r : ridx;
+        }
+#else
+        // untagged bounds (64-slot buffers, the wide kernel): tag a copy here and proceed as above -- 16 + 21
+        // instructions instead of 79
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (uint32_t)r);
+        float sec;
+        bf_min2(v, mn, sec);
+        dup = __ballot(sec < t);
+        // (a bound within 15 ulp of the threshold may pass or fail differently tagged: either is a valid filter --
+        // the thresholds reported to the proof are tagged values' thresholds minus the allowance, select.hip)
+        ridx = (mn < t) ? (__float_as_uint(mn) & 15u) : 16u;
+        seen = __ballot(mn < t);
+#endif
     }
     if (dup == 0ull) {
+#ifdef PN_DIAG_BF_NOAPPEND  // timing-only: the search, nothing else
+        asm volatile("" ::"v"(ridx));
+#else
         const bool p = ridx < 16u;
         const uint32_t pp = p ? 1u : 0u;
         const auto sw = __builtin_amdgcn_permlane32_swap(pp, pp, false, false);
@@ -685,11 +732,16 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
         if (p) {
             const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
             // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
+#ifdef PN_DIAG_BF_NOSTORE  // timing-only: everything but the store instruction
+            asm volatile("" ::"v"(o), "v"(f2s(mn)), "v"(rowb + (ridx & 3u) + 8u * (ridx >> 2)));
+#else
             ceq[o] = make_uint2(f2s(mn), rowb + (ridx & 3u) + 8u * (ridx >> 2));
+#endif
         }
         BF_COUNT(1, __popcll(seen));
         cnt += pp + other;
         ns += 1;
+#endif
     } else
 #endif
 #pragma unroll
@@ -804,29 +856,36 @@ __device__ __forceinline__ void bf_flush(BfPend &pd, float &tau, uint32_t &cnt, 
     }
 }
 
-// Wait until this wave's LDS-DMA of the next tile has landed WITHOUT waiting for the (younger) candidate
-// stores: vector-memory operations of a wave retire in order, so "at most ns outstanding" is enough when ns
-// store instructions were issued after the DMA.  s_waitcnt takes an immediate: 16 cases, larger counts wait
-// for a few of the oldest stores as well.
+// Wait until this wave's LDS-DMA has landed WITHOUT waiting for the youngest candidate stores: vector-memory
+// operations of a wave retire in order, so "at most N outstanding" is enough for any N <= ns when ns store
+// instructions were issued after the DMA.  s_waitcnt takes an immediate; three cases (N = min(ns, 2)) cover what
+// matters -- the one or two stores of a rare-path entry right in front of the barrier are not waited for, older ones
+// (half a tile ago or more) have long landed.  (A 16-way switch on ns compiled into a tree of ~10 scalar branches on
+// every tile's critical path.)
+template <bool EXACT = false>
 __device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
-    switch (ns < 15u ? ns : 15u) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    }
+    if (ns == 0u)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (ns == 1u)
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (!EXACT || ns == 2u)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else  // the wide kernel filters eight blocks right in front of a chunk barrier: up to 16 stores just issued
+        switch (ns < 15u ? ns : 15u) {
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        }
 }
 
 // cand: [nseg][nq_pad][64*M] (key, row) pairs; ccnt/ctau: [nseg][nq_pad], pre-initialised to 0 / sortable(+inf)
@@ -845,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                                                              float *__restrict__ scout_out) {
     constexpr int C = 2 * KS, CP = C + 1;
     constexpr uint32_t CAP = 64u * M;
+    constexpr bool TAG = M >= kBfTagFromM;
     constexpr int TB = kBP * CP * 16;  // bytes per tile image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     char *tiles = reinterpret_cast<char *>(smem_raw);  // [3][TB]
@@ -922,6 +982,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         const size_t cell0 = (size_t)seg * nq_pad + q0;          // its (segment, query) cell
 #if defined(PN_DIAG_BF_COUNT)
         const unsigned long long trun0_ = bf_stamp();
+        unsigned long long treal0_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal0_)::"memory");
 #endif
 
         // ---- per-run state: B fragments, thresholds and counts in registers
@@ -1106,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #if defined(PN_DIAG_BF_COUNT)
             unsigned long long tc0_ = bf_stamp_nw();
 #endif
-            bf_chain_p<KS, CI, CP>(arow0, pre, b0, b1, cc, a00, a01, a10, a11, m0, m1, arow1, tb, 1, h);
+            bf_chain_p<KS, CI, CP, TAG>(arow0, pre, b0, b1, cc, a00, a01, a10, a11, m0, m1, arow1, tb, 1, h);
 #if defined(PN_DIAG_BF_COUNT)
             {
                 unsigned long long tc1_ = bf_stamp_nw();
@@ -1118,8 +1180,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
-                if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                if (__any(m0 < tau0)) bf_slow<M, RAD, TAG>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(m1 < tau1)) bf_slow<M, RAD, TAG>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
             // mid-tile barrier
 #if defined(PN_DIAG_BF_COUNT)
@@ -1145,7 +1207,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #if defined(PN_DIAG_BF_COUNT)
             unsigned long long tc2_ = bf_stamp_nw();
 #endif
-            bf_chain_p<KS, CI, CP>(arow1, pre, b0, b1, cc, a10, a11, a00, a01, p0, p1, ntb + (jq * CP + h) * 16, ntb, 0, h);
+            bf_chain_p<KS, CI, CP, TAG>(arow1, pre, b0, b1, cc, a10, a11, a00, a01, p0, p1, ntb + (jq * CP + h) * 16, ntb, 0, h);
 #if defined(PN_DIAG_BF_COUNT)
             {
                 unsigned long long tc3_ = bf_stamp_nw();
@@ -1156,12 +1218,19 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #endif
             if (__any(p0 < tau0 || p1 < tau1)) {
                 const uint32_t row0 = rt * kBP;
-                if (__any(p0 < tau0)) bf_slow<M, RAD>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(p1 < tau1)) bf_slow<M, RAD>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                if (__any(p0 < tau0)) bf_slow<M, RAD, TAG>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+                if (__any(p1 < tau1)) bf_slow<M, RAD, TAG>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
             }
             cur = nxt;
         }
         {  // drain: block 1 of the last tile
+            if (TAG) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    a10[i] = __uint_as_float((__float_as_uint(a10[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                    a11[i] = __uint_as_float((__float_as_uint(a11[i]) & 0xFFFFFFF0u) | (uint32_t)i);
+                }
+            }
             float m0 = a10[0], m1 = a11[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
@@ -1169,8 +1238,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m1 = fminf(m1, a11[i]);
             }
             const uint32_t row0 = (rt1 - 1) * kBP + 32;
-            if (__any(m0 < tau0)) bf_slow<M, RAD>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-            if (__any(m1 < tau1)) bf_slow<M, RAD>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+            if (__any(m0 < tau0)) bf_slow<M, RAD, TAG>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
+            if (__any(m1 < tau1)) bf_slow<M, RAD, TAG>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
         }
         } else {
         // ---- prologue: first tile -> LDS[0]
@@ -1339,6 +1408,11 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 const unsigned long long te1_ = bf_stamp();
                 BF_COUNT(5, te1_ - te0_);
                 BF_COUNT(7, te1_ - trun0_);
+                {
+                    unsigned long long treal1_;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal1_)::"memory");
+                    BF_COUNT(11, treal1_ - treal0_);  // 100 MHz ticks: in-kernel clock = slot 7 / slot 11 x 100 MHz
+                }
             }
             BF_DBG_FLUSH(lane);
 #endif
@@ -1473,7 +1547,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             }
         for (uint32_t c = 0; c < nkc; ++c) {
             // chunk barrier: every wave's share of this stage has landed and nobody still reads the other stage
-            bf_wait_dma(ns);
+            bf_wait_dma<true>(ns);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

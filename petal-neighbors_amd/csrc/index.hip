@@ -559,7 +559,7 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
         // a call that handed more than 1/16 of its queries to the next tier: this corpus defeats the current plan
         // -- widen it, then turn the tier off (sticky; takes effect from the next call on)
         const size_t nf = *r.h_nflag;
-#if !defined(PN_DIAG_BF_NOSLOW) && !defined(PN_DIAG_BF_NOSTORE) && !defined(PN_DIAG_BF_NOBARRIER) && !defined(PN_DIAG_BF_NOWAIT)  // timing-only builds flag queries by design
+#if !defined(PN_DIAG_BF_NOSLOW) && !defined(PN_DIAG_BF_NOSTORE) && !defined(PN_DIAG_BF_NOBARRIER) && !defined(PN_DIAG_BF_NOWAIT) && !defined(PN_DIAG_BF_NOAPPEND)  // timing-only builds flag queries by design
         if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
 #else
         (void)nf;

@@ -32,3 +32,4 @@ print("  tile barrier incl. DMA wait %10.0f cycles = %4.1f %% of the run" % (cyc
 print("  tile top to chain 1 (fragment + norm reads issued, LDS-DMA issue, check, rare path) %10.0f cycles = %4.1f %% of the run" % (cyc(8) / waves, 100.0 * cyc(8) / waves / run))
 print("  chain 1 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(9) / waves, 100.0 * cyc(9) / waves / run, cyc(9) / waves / 1302))
 print("  chain 2 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(10) / waves, 100.0 * cyc(10) / waves / run, cyc(10) / waves / 1302))
+print("  in-kernel clock (s_memtime / s_memrealtime x 100 MHz) %.3f GHz; run = %.3f ms" % (cyc(7) / max(cyc(11), 1) * 0.1, cyc(11) / waves * 1e-5))
