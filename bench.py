@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- exact k-NN queries/sec on MI355X, with roofline and CPU baseline.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 1 000 000 points x 128 dims f32, 10 000 queries, k = 10, synthetic uniform [0,1)
 generated in HBM (counter hash, seeds 0x5EED0001 / 0x5EED0002).  A "step" is one
 pass of the hot path over the whole query batch: filter/scan kernel, exact
-re-rank + selection, and (N > 1) the all-gather + merge of per-shard top-k.
-Inputs are resident in HBM when the timed region starts.  With N > 1 the corpus
-is row-sharded over the ranks (total work fixed: strong scaling).
+re-rank + selection, and (N > 1) the all-gather + merge of per-shard top-k --
+enqueued through the C ABI's asynchronous entry points (pn_query_device_f32, or
+pn_sharded_query_device_f32, which owns the RCCL all-gather; --comm torch keeps
+the exchange in torch.distributed instead).  Inputs are resident in HBM when the
+timed region starts.  With N > 1 the corpus is row-sharded over the ranks (total
+work fixed: strong scaling).  --config picks another shape (CONFIGS below; c1 = the
+reference's own bench shapes, one point per call: the plumbing).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- dominant kernel: algorithmic flops (2*N*D per query, SURVEY.md
-                  8d) / its average hipEvent duration, against the f32 MFMA peak;
+                  8d) / its average hipEvent duration, against the MFMA peak of
+                  the dtype the kernel contracts in (bf16 first tier: 2516.8 TFLOP/s);
+                  traffic = HBM bytes per launch from the committed rocprofv3 --pmc
+                  record of the same configuration (profiles/*pmc*.json), else null;
+  verified     -- after the timed region the step's answers are checked (order,
+                  range, duplicates, distances re-derived by the scalar metric, a
+                  sample against the oracle's brute force and 2048 queries against
+                  the exact engine); --no-verify skips it (profiling runs);
   cpu_baseline -- the CPU oracle's faithful ball tree ("port": the reference is
                   Rust and cannot be built here) timed on this host's cores.
 """
