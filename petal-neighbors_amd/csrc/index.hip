@@ -1035,16 +1035,23 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // rows whose bound lies below the k-th neighbour's distance: ~1.2 k on benign data once the vectors are
     // translated by the corpus mean (measured: 11.8 for k = 10, 116 for k = 100); planned with a margin
     // (norm-in-accumulator layout: the per-query error constant uses the corpus maxima -- measured 23 / 237 rows for
-    // k = 10 / 100 against 20 / 185 with per-row constants.  Planning for that costs more in candidates (C2: +5 % step
-    // time) than the few extra unproven queries cost in the second tier, so R stays.)
-    const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
+    // k = 10 / 100 against 20 / 185 with per-row constants.  For small k planning for that costs more in candidates
+    // (C2: +5 % step time) than the few extra unproven queries cost in the second tier.  For k >= 32 the plan uses the
+    // measured 2.4 k instead of 2 k -- with a 4 sigma margin on corpora below 4M rows, which gives the same k' as before
+    // where a query's rows are spread over many segments (1M x 128, k = 100, 12 segments: 41; planning 5 sigma there
+    // costs 8 % in candidates), and with 5 sigma on larger ones, where ANY unproven query costs a scan of the whole
+    // corpus for a 64-query tile of the exact engine: 10M x 128, 10^5 queries, 5 segments: k' 87 instead of 76; 86
+    // queries per batch had overflowed a buffer and cost 22 of the batch's 265 ms, 10 per batch (k' = 80) still did.)
+    const bool ci_many = ix->bf16_ci && !ix->centered && kout >= 32;
+    const double R = (ci_many ? 2.4 : ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
+    const double n_sigma = ci_many && ix->n < ((size_t)4 << 20) ? 4.0 : 5.0;
     size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
     if (per_tile < 1) per_tile = 1;
     auto kp_for = [&](int split) -> double {
         if (ix->filter_slots > 0) return (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
         if (level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
         const double per = R / (double)(per_tile * (size_t)split);
-        const double v = per + 5.0 * std::sqrt(per) + 3.0;  // ~1e-6 per (query, segment) of holding more than that
+        const double v = per + n_sigma * std::sqrt(per) + 3.0;  // ~1e-6 per (query, segment) of holding more than that
         return v < 8.0 ? 8.0 : v;
     };
     // split the rows of a query tile into parts only while one buffer would need more than 128 slots
