@@ -1561,13 +1561,31 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
             // row (rh*128 + rb*32 + jq) and query (qg*64 + qb*32 + jq) share the swizzle key of jq
             const char *A = lds + st * kWStage + (rh * 128 + jq) * kWPitch;
             const char *B = lds + st * kWStage + kWPiece + (qg * 64 + jq) * kWPitch;
+            // Fragments one step ahead: the next step's B pair and last A fragment are requested when a step begins,
+            // its other A fragments as this step's die (two MFMAs each) -- 12 registers more than one step's set, and
+            // no step but a chunk's first waits for LDS.  (Requested at the head of their own step, as before, every
+            // step began with a round trip: the loop alone, operands already in LDS, ran at 0.60 of the peak.)
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) a[rb] = *reinterpret_cast<const bf16x8 *>(A + rb * 32 * kWPitch + slot_off[0]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) b[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + slot_off[0]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                bf16x8 a[4], b[2];
+                bf16x8 na[4], nb[2];
+#ifndef PN_DIAG_BF_WIDE_NOAHEAD
+                constexpr bool kAhead = true;
+#else
+                constexpr bool kAhead = false;
+#endif
+                if (s < 3) {
+                    if (kAhead) {
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) a[rb] = *reinterpret_cast<const bf16x8 *>(A + rb * 32 * kWPitch + slot_off[s]);
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) b[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + slot_off[s]);
+                        for (int qb = 0; qb < 2; ++qb)
+                            nb[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + slot_off[s < 3 ? s + 1 : s]);
+                        na[3] = *reinterpret_cast<const bf16x8 *>(A + 3 * 32 * kWPitch + slot_off[s < 3 ? s + 1 : s]);
+                    }
+                }
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
@@ -1594,6 +1612,25 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    if (kAhead && s < 3 && rb < 3) {  // a[rb] is dead: the next step's fragment may land in its registers
+                        __builtin_amdgcn_sched_barrier(0);
+                        na[rb] = *reinterpret_cast<const bf16x8 *>(A + rb * 32 * kWPitch + slot_off[s < 3 ? s + 1 : s]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (s < 3) {
+                    if (!kAhead) {
+#pragma unroll
+                        for (int rb = 0; rb < 4; ++rb)
+                            na[rb] = *reinterpret_cast<const bf16x8 *>(A + rb * 32 * kWPitch + slot_off[s < 3 ? s + 1 : s]);
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+                            nb[qb] = *reinterpret_cast<const bf16x8 *>(B + qb * 32 * kWPitch + slot_off[s < 3 ? s + 1 : s]);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) a[rb] = na[rb];
+                    b[0] = nb[0];
+                    b[1] = nb[1];
                 }
             }
             st ^= 1;
