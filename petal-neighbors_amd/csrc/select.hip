@@ -42,10 +42,14 @@ __device__ __forceinline__ uint32_t rank_of(const KeyT *skey, const IdxT *sidx, 
 // Shrinks n LDS entries to the (at most kout, barring duplicate entries) smallest under (key, idx), in place and
 // in their original relative order, so that rank_of runs over kout entries instead of n: a radix select on the
 // key (one ballot per 64 entries per bit), then on the index among the keys equal to the kout-th one.  One wave.
+__device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane);
 template <typename KeyT, typename IdxT>
 __device__ __forceinline__ uint32_t prune_to_topk(KeyT *skey, IdxT *sidx, uint32_t n, uint32_t kout, int lane) {
     if (n <= kout || n <= 128) return n;
     KeyT T = 0;  // becomes the kout-th smallest key
+    if (sizeof(KeyT) == 4 && n <= 256u)
+        T = (KeyT)kth_smallest_lds(reinterpret_cast<const uint32_t *>(skey), n, kout, lane);  // words in registers
+    else
     for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
         const KeyT cand = T | ((KeyT)1 << b);
         uint32_t c = 0;
@@ -272,6 +276,27 @@ __device__ __forceinline__ float exact_distance_prefetched_f32(const float *qs, 
 // per bit.  Requires 1 <= k <= n.
 __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane) {
     uint32_t T = 0;
+#ifndef PN_DIAG_SELECT_LDS
+    if (n <= 256u) {
+        // up to four words per lane, held in registers: 32 rounds of compare + ballot + scalar popcount with no LDS
+        // round trip in them (a round over LDS is latency-bound: ~100 cycles per 64 words and bit; the re-rank of the
+        // headline batch runs three such selections over ~150 candidates per query)
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
+            v[i] = e < n ? a[e] : 0xFFFFFFFFu;  // padding: never below a candidate threshold
+        }
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t cand = T | (1u << b);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c += (uint32_t)__popcll(__ballot(v[i] < cand));
+            if (c < k) T = cand;
+        }
+        return T;
+    }
+#endif
     for (int b = 31; b >= 0; --b) {
         const uint32_t cand = T | (1u << b);
         uint32_t c = 0;
