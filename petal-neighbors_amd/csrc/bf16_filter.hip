@@ -1967,10 +1967,27 @@ __global__ __launch_bounds__(64) void bf16_seed_kernel(const float *__restrict__
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
     const uint32_t per = 2 * kScoutList, n = (uint32_t)nseg * per;
+    uint32_t T = 0;
+    if (n <= 512u) {  // up to eight words per lane, in registers: no LDS round trip per bit (C2: 288 values per query)
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
+            v[i] = e < n ? f2s(lists[((size_t)(e / per) * nq_pad + q) * per + e % per]) : 0xFFFFFFFFu;
+        }
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cnd = T | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c += (uint32_t)__popcll(__ballot(v[i] < cnd));
+            if (c < rank) T = cnd;
+        }
+        if (lane == 0) out[q] = T == 0xFFFFFFFFu ? T : T + 1;
+        return;
+    }
     for (uint32_t e = lane; e < n; e += 64)
         sk[e] = f2s(lists[((size_t)(e / per) * nq_pad + q) * per + e % per]);
     __syncthreads();
-    uint32_t T = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cnd = T | (1u << bit);
         uint32_t c = 0;
