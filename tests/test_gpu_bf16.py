@@ -296,3 +296,29 @@ def test_second_tier_many_segment_path(pn, oracle_mod, k):
     q2 = np.concatenate([pts2[7:8], qs[:200]])
     tree, st = _check(pn, oracle_mod, pts2, q2, 10)
     assert 1 <= st["fallback_queries"] <= 8, st
+
+
+def test_narrow_partition_edge_cases(pn, oracle_mod):
+    """the software-pipelined main loop (three LDS buffers, barrier in mid-tile) on runs of every length: few row
+    tiles, the segment cap, and persistent slices that straddle query tiles (more query tiles than workgroups), whose
+    runs begin and end anywhere -- including runs of one and two tiles"""
+    from petal_neighbors_amd import _lib
+    # few row tiles: 66 tiles over up to 2 workgroups per query tile
+    _check(pn, oracle_mod, uniform((4200, 48), 31), uniform((300, 48), 32), 5)
+    # the segment cap with several query tiles (aligned: 3 workgroups per query tile)
+    _check(pn, oracle_mod, uniform((30000, 128), 33), uniform((1000, 128), 34), 10, opts={_lib.PN_OPT_SEGMENTS: 3})
+    # more query tiles than workgroup slots, persistent equal slices (the option switches the grid-in-rounds plan off):
+    # slices straddle query tiles, runs are cut wherever a slice ends
+    n, dim, nq, k = 4500, 16, 140000, 5
+    pts, qs = uniform((n, dim), 35), uniform((nq, dim), 36)
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine("bf16")
+    tree.set_option(_lib.PN_OPT_SEGMENTS, 2)
+    idx, dist = tree.query_batch(qs, k)
+    ref = pn.BallTree.euclidean(pts)
+    ref.set_engine("exact")
+    ridx, rdist = ref.query_batch(qs, k)
+    assert dist.tobytes() == rdist.tobytes() and np.array_equal(idx, ridx)
+    sel = np.random.default_rng(37).choice(nq, 300, replace=False)
+    oidx, odist = oracle_mod.brute_knn(pts, qs[sel], k)
+    assert dist[sel].tobytes() == odist.tobytes() and np.array_equal(idx[sel], oidx)
