@@ -366,6 +366,38 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         if (lane == 0) seg_off[64] = chunk_total;
         __syncthreads();
         const int nsc = nseg - s0 < 64 ? nseg - s0 : 64;
+        if (ckey) {
+            // four rounds of 64 candidates at a time: all their (row, key) loads are in flight together -- a round
+            // that waits for its own loads before the next one starts costs a memory round trip per 64 candidates
+            for (uint32_t e0 = 0; e0 < chunk_total; e0 += 256) {
+                uint32_t ixr[4], fkr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t e = e0 + 64u * (uint32_t)r + (uint32_t)lane;
+                    ixr[r] = 0xFFFFFFFFu;
+                    fkr[r] = 0xFFFFFFFFu;
+                    if (e < chunk_total) {
+                        int lo = 0, hi = nsc - 1;  // last cell whose offset is <= e (empty cells are skipped by <=)
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (seg_off[mid] <= e) lo = mid; else hi = mid - 1;
+                        }
+                        const size_t src = (((size_t)(s0 + lo) * nq_pad + q) * (size_t)cap + (e - seg_off[lo])) * (size_t)idx_stride;
+                        ixr[r] = cidx[src];
+                        fkr[r] = ckey[src];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t e = e0 + 64u * (uint32_t)r + (uint32_t)lane;
+                    if (e < chunk_total) {
+                        sidx[n + e] = ixr[r];
+                        sfk[n + e] = fkr[r];
+                        skey[n + e] = 0xFFFFFFFFu;
+                    }
+                }
+            }
+        } else
         for (uint32_t e0 = 0; e0 < chunk_total; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < chunk_total) {
@@ -377,13 +409,8 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
                 const size_t src = (((size_t)(s0 + lo) * nq_pad + q) * (size_t)cap + (e - seg_off[lo])) * (size_t)idx_stride;
                 const uint32_t ix = cidx[src];
                 sidx[n + e] = ix;
-                if (ckey) {
-                    sfk[n + e] = ckey[src];
-                    skey[n + e] = 0xFFFFFFFFu;
-                } else {
-                    // a row number beyond the corpus (never produced; defensive) sorts behind everything
-                    skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
-                }
+                // a row number beyond the corpus (never produced; defensive) sorts behind everything
+                skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
             }
         }
         n += chunk_total;
