@@ -355,19 +355,33 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
 // compact_query (topk_buffer.h) but the bookkeeping goes back to registers.
 // ---------------------------------------------------------------------------
 template <int M>
-__device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, int lane, uint32_t &T_out,
-                                           uint32_t &n_out) {
-    uint32_t key[M], ix[M];
-    bool valid[M];
+__device__ __forceinline__ void bf_compact_load(const uint2 *ce, uint32_t n, int lane, uint32_t (&key)[M],
+                                                uint32_t (&ix)[M]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const uint32_t slot = m * 64 + lane;
-        valid[m] = slot < n;
         uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (valid[m]) e = ce[slot];
+        if (slot < n) e = ce[slot];
         key[m] = e.x;
         ix[m] = e.y;
     }
+}
+template <int M>
+__device__ __forceinline__ void bf_compact_finish(uint2 *ce, const uint32_t (&key)[M], const uint32_t (&ix)[M],
+                                                  uint32_t n, uint32_t kp, int lane, uint32_t &T_out, uint32_t &n_out);
+template <int M>
+__device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, int lane, uint32_t &T_out,
+                                           uint32_t &n_out) {
+    uint32_t key[M], ix[M];
+    bf_compact_load<M>(ce, n, lane, key, ix);
+    bf_compact_finish<M>(ce, key, ix, n, kp, lane, T_out, n_out);
+}
+template <int M>
+__device__ __forceinline__ void bf_compact_finish(uint2 *ce, const uint32_t (&key)[M], const uint32_t (&ix)[M],
+                                                  uint32_t n, uint32_t kp, int lane, uint32_t &T_out, uint32_t &n_out) {
+    bool valid[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) valid[m] = (uint32_t)(m * 64 + lane) < n;
     uint32_t T = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = T | (1u << bit);
@@ -425,15 +439,16 @@ constexpr int kLA = PN_DIAG_KLA;
 #else
 constexpr int kLA = 3;
 #endif
-// The main loop of the narrow kernel tags the bounds it scans (bf_chain_p) when survivors are frequent -- buffers of
-// 128 slots and more, i.e. k' > 32, and radius queries -- so that a rare-path entry finds its survivor without a search
-// (bf_slow).  The 32 tag instructions per chain are not free now that the chains are tight: measured on one device,
-// 1M rows, tags on vs off: D = 128, k = 100 3.59 vs 4.03 ms, but k = 10 2.57 vs 2.52 (D = 96: 2.23 vs 2.30, D = 64:
-// 1.94 vs 1.96 -- within a few per cent either way for 64-slot buffers, which therefore stay untagged).
-#ifdef PN_DIAG_BF_NOTAG
-constexpr int kBfTagFromM = 1000;
-#else
+// Tags (the register number in a bound's low four mantissa bits) are written inside a rare-path entry (bf_slow).
+// Measured alternative, -DPN_DIAG_BF_SHADOWTAG: the main loop writes them while it takes the minimum (bf_chain_p), for
+// kernels with buffers of 128 slots and more, so that an entry needs no tagging pass.  With survivors frequent (1M x
+// 128, k = 100) that was 2 % faster than tagging inside the entry -- but the 32 tagged values per chain cost the
+// kernel ~50 registers (the compiler keeps them beside the accumulator tuples they came from), the KS >= 5 variants
+// spill, and on long runs it is 10 % slower (10M x 128, 10^5 queries, k = 100: 239 vs 215 ms).
+#ifdef PN_DIAG_BF_SHADOWTAG
 constexpr int kBfTagFromM = 2;
+#else
+constexpr int kBfTagFromM = 1000;
 #endif
 constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
 // smallest (mn) and second smallest (sec) of 16 finite values: triples give (min3, med3); the second smallest overall
@@ -1384,24 +1399,34 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #else
             constexpr bool kFinalCompact = true;
 #endif
-            unsigned long long need = RAD || !kFinalCompact ? 0ull : __ballot(h == 0 && cnt0 > kp);
-            while (need) {
-                const int j = __builtin_ctzll(need);
-                need &= need - 1;
-                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, j);
-                uint32_t T, nn;
-                bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
-                if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
-            }
-            need = RAD || !kFinalCompact ? 0ull : __ballot(h == 0 && cnt1 > kp);
-            while (need) {
-                const int j = __builtin_ctzll(need);
-                need &= need - 1;
-                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, j);
-                uint32_t T, nn;
-                bf_compact<M>(ce_blk1 + (size_t)j * CAP, cj, kp, lane, T, nn);
-                if (jq == j) { tau1 = s2f(T); cnt1 = nn; }
-            }
+            // 64-slot buffers four at a time: their entries are requested together, then selected one after the other
+            // (a buffer at a time pays a memory round trip per buffer: up to 128 in a row at the end of every run;
+            // larger buffers stay one at a time -- four of them in registers made the kernel spill)
+            constexpr int NB = M == 1 ? 4 : 1;
+            auto final_compact = [&](uint2 *ce_blk, float &tau, uint32_t &cnt) {
+                unsigned long long need = RAD || !kFinalCompact ? 0ull : __ballot(h == 0 && cnt > kp);
+                while (need) {
+                    int jj[NB];
+                    uint32_t cj[NB], key[NB][M], ixs[NB][M];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        jj[b] = need ? __builtin_ctzll(need) : -1;
+                        if (need) need &= need - 1;
+                        cj[b] = jj[b] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cnt, jj[b] >= 0 ? jj[b] : 0) : 0u;
+                        if (jj[b] >= 0) bf_compact_load<M>(ce_blk + (size_t)jj[b] * CAP, cj[b], lane, key[b], ixs[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (jj[b] >= 0) {
+                            uint32_t T, nn;
+                            bf_compact_finish<M>(ce_blk + (size_t)jj[b] * CAP, key[b], ixs[b], cj[b], kp, lane, T, nn);
+                            if (jq == jj[b]) { tau = s2f(T); cnt = nn; }
+                        }
+                    }
+                }
+            };
+            final_compact(ce_blk0, tau0, cnt0);
+            final_compact(ce_blk1, tau1, cnt1);
 #if defined(PN_DIAG_BF_NOSTORE) || defined(PN_DIAG_BF_NOSLOW)
             cnt0 = 0;  // timing-only builds: the buffers hold no valid rows
             cnt1 = 0;

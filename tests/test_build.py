@@ -17,7 +17,7 @@ def asm():
     spec.loader.exec_module(b)
     b.build(keep_asm=True)
     out = {}
-    for name in ("exact_scan", "select"):
+    for name in ("exact_scan", "select", "bf16_filter"):
         out[name] = open(os.path.join(ROOT, "petal-neighbors_amd", "build", name + ".s")).read()
     return out
 
@@ -64,6 +64,24 @@ def test_exact_kernels_do_not_spill(asm):
     for unit, text in asm.items():
         for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", text):
             assert int(m.group(1)) == 0, unit
+
+
+def test_bf16_filter_kernels_neither_spill_nor_lose_their_occupancy(asm):
+    """Every instantiation of the first-tier kernels stays within 256 VGPRs without scratch: two waves per SIMD (two
+    workgroups per CU for the narrow kernel, one 8-wave workgroup for the wide one) is what their LDS and register
+    budgets are planned for.  (Round 2: tags written in the matrix pipe's shadow cost ~50 registers, spilled for
+    KS >= 5 and made the full-size k = 100 configuration 10 % slower before anyone looked.)"""
+    text = asm["bf16_filter"]
+    kernels = 0
+    for blk in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "bf16_filter_kernel" not in name and "bf16_wide_kernel" not in name:
+            continue
+        kernels += 1
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        assert g("vgpr_spill_count") == 0 and g("private_segment_fixed_size") == 0, name
+        assert g("vgpr_count") <= 256, name
+    assert kernels >= 100
 
 
 def test_product_library_carries_no_diagnostic_flags():
