@@ -313,8 +313,27 @@ def main():
     torch.cuda.synchronize()
     # "abi": the whole step (local shard, ONE ncclAllGather, merge) is one asynchronous call into the C ABI;
     # "torch": the exchange is torch.distributed's all_gather_into_tensor (kept for comparison)
-    engine = AbiShardEngine(dev.index) if args.comm == "abi" else HipShardEngine(dev.index)
-    index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P), engine=engine)
+    comm_note = None
+    index = None
+    if args.comm == "abi":
+        try:
+            index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P), engine=AbiShardEngine(dev.index))
+        except Exception as e:  # PN_ERR_COMM and friends: the bench still has to produce its line
+            comm_note = f"{type(e).__name__}: {e}"
+        if dist and world > 1:  # every rank takes the same path
+            ok = torch.tensor([0 if index is None else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                index = None
+                comm_note = comm_note or "another rank could not build its pn_sharded handle"
+        if index is None:
+            if world == 1:
+                sys.exit(f"bench.py: {comm_note}")
+            print(f"bench.py: rank {rank}: C-ABI exchange unavailable ({comm_note}); "
+                  f"falling back to torch.distributed for the exchange", file=sys.stderr)
+            args.comm = "torch"
+    if index is None:
+        index = ShardedBallTree(n, lambda lo, hi: gen(lo, hi, SEED_P), engine=HipShardEngine(dev.index))
     tree = index.engine.tree  # None for a rank without rows on the torch path
     if tree is not None:
         tree.set_engine(args.engine)
@@ -411,7 +430,8 @@ def main():
                        "exchange": ("none (one shard)" if world == 1 else
                                     "one ncclAllGather per step behind the C ABI (pn_sharded_query_device_f32)"
                                     if args.comm == "abi" else "torch.distributed.all_gather_into_tensor"),
-                       "rccl_world_size": rccl_world},
+                       "rccl_world_size": rccl_world,
+                       **({"exchange_note": f"fell back from the C-ABI exchange: {comm_note}"} if comm_note else {})},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
