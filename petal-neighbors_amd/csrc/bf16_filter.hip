@@ -42,8 +42,11 @@
 //    stores into the (segment, query) buffers the select kernel reads -- no LDS atomics, no fences on
 //    the fast path, no flush copy; the tile barrier waits for the LDS-DMA but not for those stores
 //    (bf_wait_dma);
-//  * the fast path per 16 bounds is a v_min3 tree and one compare -- the loop is bound by vector-instruction issue,
-//    not by the matrix pipe; the row a surviving minimum belongs to is found in the rare path (bf_slow);
+//  * the main loop is software-pipelined over three tile buffers: every chain of 2 KS MFMAs starts from fragments
+//    and row norms requested during the previous chain, the workgroup's one barrier per tile sits between the tile's
+//    two chains (bf_chain_p and the loop in the kernel say why);
+//  * the fast path per 16 bounds is a v_min3 tree and one compare in the chain's shadow; the row a surviving minimum
+//    belongs to is found in the rare path (bf_slow: tags + a second-smallest network, one append for all lanes);
 //  * thresholds do not start at +inf: a scout pass over the run's first tiles seeds them -- within the
 //    launch from the run's own rows, or, with several segments per query, in a scout-only launch whose
 //    lists bf16_seed_kernel merges per query over all segments (host: bf16_plan in index.hip).
