@@ -95,7 +95,8 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
         asm = os.path.join(BUILD, os.path.splitext(src)[0] + ".s")
-        if keep_asm and src.endswith(".hip") and (force or _stale(asm, [sp, me] + HEADERS)):
+        want_asm = keep_asm is True or (keep_asm and os.path.splitext(src)[0] in keep_asm)  # True: every unit
+        if want_asm and src.endswith(".hip") and (force or _stale(asm, [sp, me] + HEADERS)):
             cmd = [cc] + COMMON + extra + DIAG + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
