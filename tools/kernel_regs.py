@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Register counts, spills and scratch of the kernels in one compilation unit (from the -S output of the product flags).
+"""Register counts, spills and scratch of the kernels in one compilation unit (compiled with the product flags +
+$PN_DIAG_FLAGS; tests/test_build.py reads the same numbers from the product object without compiling).
 usage: tools/kernel_regs.py [unit.hip] [name substring ...]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
