@@ -1044,7 +1044,8 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // queries per batch had overflowed a buffer and cost 22 of the batch's 265 ms, 10 per batch (k' = 80) still did.)
     const bool ci_many = ix->bf16_ci && !ix->centered && kout >= 32;
     const double R = (ci_many ? 2.4 : ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
-    const double n_sigma = ci_many && ix->n < ((size_t)4 << 20) ? 4.0 : 5.0;
+    // (small k on such corpora: half a sigma more -- one unproven query in 10^6 is a 10^7-row scan there)
+    const double n_sigma = ix->n < ((size_t)4 << 20) ? (ci_many ? 4.0 : 5.0) : (ci_many ? 5.0 : 5.5);
     size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
     if (per_tile < 1) per_tile = 1;
     auto kp_for = [&](int split) -> double {
