@@ -238,8 +238,10 @@ int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_pa
  * Queries on this engine never use a tree; the first call of any function below builds -- once, on the host, from the
  * index's own copy of the points -- the implicit complete binary ball tree exactly as the reference does
  * (src/ball_tree.rs:38-63, 445-461, 504-613: node i has children 2i+1 / 2i+2, median split on the column of maximum
- * spread, sequential-mean centroid, radius = largest distance to it), so every answer equals the reference's node for
- * node.  O(n d log n) time and (nodes x d) extra host memory, paid only by callers of this API.
+ * spread, sequential-mean centroid, radius = largest distance to it UNDER THE INDEX'S METRIC -- Node::init and
+ * node_distance_lower_bound call metric.distance, src/ball_tree.rs:309, 459: on a pn_index_create_cosine_* index
+ * radius_of, compare_nodes and node_distance_lower_bound are Cosine::distance values, the split and the permutation do
+ * not depend on the metric), so every answer equals the reference's node for node.  O(n d log n) time and (nodes x d) extra host memory, paid only by callers of this API.
  * A node number >= num_nodes is PN_ERR_INVALID (the reference panics).
  *   children_of:   *is_some = 0 for a leaf (None), else 1 with (*left, *right) = (2n+1, 2n+2)
  *   points_of:     *idx points INTO the tree's permutation (valid until pn_index_destroy), *count entries

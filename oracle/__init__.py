@@ -76,6 +76,8 @@ def _declare(L):
         f.argtypes = [P, _SZ, _SZ, _SZ, C.c_ssize_t, C.POINTER(_I)]
         f = getattr(L, f"oracle_tree_build_mt_{sfx}"); f.restype = _VP
         f.argtypes = [P, _SZ, _SZ, _SZ, C.c_ssize_t, _I, C.POINTER(_I)]
+        f = getattr(L, f"oracle_tree_build_metric_{sfx}"); f.restype = _VP
+        f.argtypes = [P, _SZ, _SZ, _SZ, C.c_ssize_t, _I, _I, C.POINTER(_I)]
         f = getattr(L, f"oracle_tree_free_{sfx}"); f.restype = None; f.argtypes = [_VP]
         f = getattr(L, f"oracle_tree_num_nodes_{sfx}"); f.restype = _SZ; f.argtypes = [_VP]
         f = getattr(L, f"oracle_tree_idx_{sfx}"); f.restype = C.POINTER(_SZ); f.argtypes = [_VP]
@@ -240,9 +242,11 @@ def halve_node_indices(idx, col):
 
 
 class Tree:
-    """Faithful restatement of ``BallTree<A, Euclidean>`` (src/ball_tree.rs)."""
+    """Faithful restatement of ``BallTree<A, M>`` (src/ball_tree.rs), M = Euclidean (default) or Cosine
+    (``metric="cosine"``: BallTree::new(points, Cosine) -- every distance of the build and of the walks goes through
+    Metric::distance, src/ball_tree.rs:165,218,276,309,459,464,474)."""
 
-    def __init__(self, points, build_threads_log2=0):
+    def __init__(self, points, build_threads_log2=0, metric="euclidean"):
         a = np.asarray(points)
         if a.ndim != 2:
             raise ValueError("points must be 2-D")
@@ -257,9 +261,10 @@ class Tree:
         self.points = np.ascontiguousarray(a)
         err = _I(0)
         L = lib()
-        self._h = getattr(L, f"oracle_tree_build_mt_{self._s}")(
+        self.metric = {"euclidean": 0, "cosine": 1}[metric]
+        self._h = getattr(L, f"oracle_tree_build_metric_{self._s}")(
             _ptr(self.points, self._ct), n, d, max(d, 1) if self.points.size else 0, 1,
-            int(build_threads_log2), C.byref(err))
+            int(build_threads_log2), self.metric, C.byref(err))
         if not self._h:
             raise OracleArrayError(err.value)
         self.n, self.dim = n, d

@@ -166,11 +166,19 @@ typedef struct {
     /* instrumentation (not in the reference) */
     uint64_t n_centroid_evals, n_point_evals;
     int par_depth; /* 0 = build on one thread like the reference */
+    int metric;    /* BallTree::metric (:23): 0 = Euclidean, 1 = Cosine */
 } FN(tree_t);
 
+/* metric.distance(a, b) for the tree's metric tag (src/ball_tree.rs:165,218,276,309,459,464,474 all go through
+ * Metric::distance); both vectors have the tree's dimension */
+static inline T FN(metric_distance)(int metric, const T *a, const T *b, size_t dim)
+{
+    return metric == 1 ? FN(oracle_cosine)(a, dim, b, dim) : FN(oracle_euclidean)(a, b, dim);
+}
+
 /* src/ball_tree.rs:445-461  Node::init */
-void FN(oracle_node_init)(const T *pts, size_t dim, size_t ld, const size_t *idx,
-                          size_t len, T *centroid, T *radius)
+void FN(oracle_node_init_metric)(const T *pts, size_t dim, size_t ld, const size_t *idx,
+                                 size_t len, T *centroid, T *radius, int metric)
 {
     for (size_t c = 0; c < dim; ++c) centroid[c] = (T)0;
     for (size_t a = 0; a < len; ++a) { /* :446-453 row-by-row accumulation */
@@ -181,10 +189,15 @@ void FN(oracle_node_init)(const T *pts, size_t dim, size_t ld, const size_t *idx
     for (size_t c = 0; c < dim; ++c) centroid[c] /= flen;
     T mx = (T)0; /* :458-460 fold(0, |max, i| A::max(dist, max)) */
     for (size_t a = 0; a < len; ++a) {
-        T d = FN(oracle_euclidean)(centroid, pts + idx[a] * ld, dim);
+        T d = FN(metric_distance)(metric, centroid, pts + idx[a] * ld, dim); /* :459 metric.distance(centroid, row) */
         mx = FMAX(d, mx); /* Float::max ignores NaN like fmax */
     }
     *radius = mx;
+}
+void FN(oracle_node_init)(const T *pts, size_t dim, size_t ld, const size_t *idx,
+                          size_t len, T *centroid, T *radius)
+{
+    FN(oracle_node_init_metric)(pts, dim, ld, idx, len, centroid, radius, 0);
 }
 
 /* src/ball_tree.rs:577-613  max_spread_column; returns (size_t)-1 on the
@@ -243,8 +256,8 @@ static void FN(build_subtree)(FN(tree_t) *t, size_t root, size_t start, size_t e
 {
     FN(node_t) *nd = &t->nodes[root];
     nd->centroid = (T *)malloc((t->dim ? t->dim : 1) * sizeof(T));
-    FN(oracle_node_init)(t->pts, t->dim, t->ld, t->idx + start, end - start,
-                         nd->centroid, &nd->radius);
+    FN(oracle_node_init_metric)(t->pts, t->dim, t->ld, t->idx + start, end - start,
+                                nd->centroid, &nd->radius, t->metric);
     nd->start = start;
     nd->end = end;
     size_t left = root * 2 + 1;
@@ -287,8 +300,16 @@ FN(tree_t) *FN(oracle_tree_build)(const T *pts, size_t n, size_t dim, size_t ld,
 {
     return FN(oracle_tree_build_mt)(pts, n, dim, ld, col_stride, 0, err);
 }
+FN(tree_t) *FN(oracle_tree_build_metric)(const T *pts, size_t n, size_t dim, size_t ld,
+                                         ptrdiff_t col_stride, int par_depth, int metric, int *err);
 FN(tree_t) *FN(oracle_tree_build_mt)(const T *pts, size_t n, size_t dim, size_t ld,
                                      ptrdiff_t col_stride, int par_depth, int *err)
+{
+    return FN(oracle_tree_build_metric)(pts, n, dim, ld, col_stride, par_depth, 0, err);
+}
+/* BallTree::new(points, metric) (src/ball_tree.rs:38-63): metric 0 = Euclidean, 1 = Cosine */
+FN(tree_t) *FN(oracle_tree_build_metric)(const T *pts, size_t n, size_t dim, size_t ld,
+                                         ptrdiff_t col_stride, int par_depth, int metric, int *err)
 {
     *err = 0;
     if (n == 0) { *err = 1; return NULL; }                       /* :44-46 */
@@ -297,6 +318,7 @@ FN(tree_t) *FN(oracle_tree_build_mt)(const T *pts, size_t n, size_t dim, size_t 
     FN(tree_t) *t = (FN(tree_t) *)calloc(1, sizeof(*t));
     t->pts = pts; t->n = n; t->dim = dim; t->ld = ld;
     t->par_depth = par_depth;
+    t->metric = metric;
     unsigned height = 0; /* usize::BITS - leading_zeros(n) (:51) */
     for (size_t v = n; v; v >>= 1) ++height;
     t->n_nodes = ((size_t)1 << height) - 1; /* :52 */
@@ -335,7 +357,7 @@ void FN(oracle_tree_eval_counts)(FN(tree_t) *t, uint64_t *centroid, uint64_t *po
 /* src/ball_tree.rs:473-481  Node::distance_lower_bound */
 static inline T FN(node_lb)(const FN(tree_t) *t, const FN(node_t) *nd, const T *q, uint64_t *cnt)
 {
-    T cd = FN(oracle_euclidean)(q, nd->centroid, t->dim);
+    T cd = FN(metric_distance)(t->metric, q, nd->centroid, t->dim);
     ++*cnt;
     T lb = cd - nd->radius;
     return (lb < (T)0) ? (T)0 : lb;
@@ -431,7 +453,7 @@ static void FN(knn_subtree)(FN(tree_t) *t, const T *q, size_t root, T *radius, s
     if (nd->is_leaf) {
         for (size_t a = nd->start; a < nd->end; ++a) { /* :217-226 */
             size_t i = t->idx[a];
-            FN(nb_t) nb = { i, FN(oracle_euclidean)(q, t->pts + i * t->ld, t->dim) };
+            FN(nb_t) nb = { i, FN(metric_distance)(t->metric, q, t->pts + i * t->ld, t->dim) };
             ++t->n_point_evals;
             if (h->len < k) {
                 FN(heap_push)(h, nb);
@@ -481,7 +503,7 @@ static int FN(nn_subtree)(FN(tree_t) *t, const T *q, size_t root, T radius, size
         T min_d = (T)INFINITY; /* fold seed (0, inf) :162-163 */
         for (size_t a = nd->start; a < nd->end; ++a) {
             size_t i = t->idx[a];
-            T d = FN(oracle_euclidean)(q, t->pts + i * t->ld, t->dim);
+            T d = FN(metric_distance)(t->metric, q, t->pts + i * t->ld, t->dim);
             ++t->n_point_evals;
             if (d < min_d) { min_i = i; min_d = d; } /* :167 */
         }
@@ -525,7 +547,7 @@ size_t FN(oracle_tree_query_radius)(FN(tree_t) *t, const T *q, T radius, uint64_
     for (;;) {
         size_t sub = stack[--sp];
         FN(node_t) *nd = &t->nodes[sub];
-        T cd = FN(oracle_euclidean)(q, nd->centroid, t->dim); /* :463-471 */
+        T cd = FN(metric_distance)(t->metric, q, nd->centroid, t->dim); /* :463-471 */
         ++t->n_centroid_evals;
         T lb = cd - nd->radius;
         if (lb < (T)0) lb = (T)0;
@@ -539,7 +561,7 @@ size_t FN(oracle_tree_query_radius)(FN(tree_t) *t, const T *q, T radius, uint64_
         } else if (nd->is_leaf) { /* :274-282 */
             for (size_t a = nd->start; a < nd->end; ++a) {
                 size_t i = t->idx[a];
-                T d = FN(oracle_euclidean)(q, t->pts + i * t->ld, t->dim);
+                T d = FN(metric_distance)(t->metric, q, t->pts + i * t->ld, t->dim);
                 ++t->n_point_evals;
                 if (d < radius) out[cnt++] = i;
             }

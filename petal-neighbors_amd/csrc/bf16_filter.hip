@@ -704,8 +704,30 @@ __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA],
                     nc[4 * g + 2] = v[2];
                     nc[4 * g + 3] = v[3];
                 }
+#ifdef PN_DIAG_BF_1632  // TIMING ONLY (wrong results): the same flops as two v_mfma_f32_16x16x32_bf16 per 32x32x16
+            {
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x16 s0 = ks ? w0 : c, s1 = ks ? w1 : c;
+                f32x4_t q00 = __builtin_shufflevector(s0, s0, 0, 1, 2, 3), q01 = __builtin_shufflevector(s0, s0, 4, 5, 6, 7);
+                f32x4_t q10 = __builtin_shufflevector(s1, s1, 0, 1, 2, 3), q11 = __builtin_shufflevector(s1, s1, 4, 5, 6, 7);
+                q00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], b0[ks], q00, 0, 0, 0);
+                q01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], b0[ks], q01, 0, 0, 0);
+                q10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], b1[ks], q10, 0, 0, 0);
+                q11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], b1[ks], q11, 0, 0, 0);
+                w0 = s0;
+                w1 = s1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w0[i] = q00[i];
+                    w0[4 + i] = q01[i];
+                    w1[i] = q10[i];
+                    w1[4 + i] = q11[i];
+                }
+            }
+#else
             w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b0[ks], ks ? w0 : c, 0, 0, 0);
             w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks], b1[ks], ks ? w1 : c, 0, 0, 0);
+#endif
 #ifndef PN_DIAG_BF_NOKEEPC
             // c outlives both MFMAs that read it: otherwise the second one accumulates IN c's registers, its proper
             // registers serve as fragment space meanwhile, and sixteen moves that wait for the matrix pipe bring the

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -89,12 +90,27 @@ extern "C" int pn_device_count(int *count) {
 // ---------------------------------------------------------------------------
 // index object
 // ---------------------------------------------------------------------------
+// A buffer that only grows.  The asynchronous entry points return while kernels that were handed the OLD allocation
+// may still be running, and hipFree would wait for the whole device (an "enqueue and return" call must not): an
+// outgrown allocation is RETIRED to its owner's list instead and freed once the owner's end-of-use event has passed
+// (ws_acquire) or at destruction.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    std::vector<void *> *retired = nullptr;  // owner's list; nullptr: free at once (construction-time buffers)
     int ensure(size_t need) {
         if (need <= bytes && p) return PN_OK;
-        if (p) (void)hipFree(p);
+        if (p) {
+            bool kept = false;
+            if (retired) {
+                try {
+                    retired->push_back(p);
+                    kept = true;
+                } catch (const std::bad_alloc &) {
+                }
+            }
+            if (!kept) (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
         size_t want = need + need / 8 + 256;
@@ -127,6 +143,16 @@ struct Workspace {
     DevBuf *all[28] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
                        &w2_cnt, &w2_tau, &w_lo, &w_bq, &w_qn, &w_qbad, &w_gq, &w_gidx, &w_gdist, &w_gsel, &w_seed,
                        &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist, &w_fparts};
+    std::vector<void *> retired;  // outgrown allocations, freed once `done` has passed (DevBuf::ensure)
+    Workspace() {
+        for (DevBuf *b : all) b->retired = &retired;
+    }
+    Workspace(const Workspace &) = delete;
+    Workspace &operator=(const Workspace &) = delete;
+    void free_retired() {
+        for (void *q : retired) (void)hipFree(q);
+        retired.clear();
+    }
 };
 
 // What a finished chunk of a call leaves for the host to pick up LATER (never inside the call): hipEvent brackets of
@@ -175,7 +201,10 @@ struct pn_index {
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
-        HostTree *tree = nullptr;  // the reference's ball tree, built on first use of the introspection API (tree.cpp)
+        // the reference's ball tree, built on first use of the introspection API (tree.cpp): published once, built under
+        // tree_mu -- never under `mu`, which every query takes (an O(n d log n) host build must not block them)
+        std::atomic<HostTree *> tree{nullptr};
+        std::mutex tree_mu;
     };
     mutable Shared sh;
 };
@@ -456,6 +485,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     (void)hipDeviceSynchronize();
     for (Workspace *ws : ix->sh.all_ws) {
         for (DevBuf *b : ws->all) b->release();
+        ws->free_retired();
         if (ws->done) (void)hipEventDestroy(ws->done);
         if (ws->stream) (void)hipStreamDestroy(ws->stream);
         delete ws;
@@ -473,7 +503,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_cnorm) (void)hipFree(ix->d_cnorm);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    if (ix->sh.tree) host_tree_free(ix->sh.tree);
+    if (HostTree *t = ix->sh.tree.load()) host_tree_free(t);
     delete ix;
 }
 
@@ -504,6 +534,8 @@ static int ws_acquire(const pn_index *ix, hipStream_t *s, bool own_stream, Works
         ix->sh.all_ws.push_back(ws);
     }
     if (own_stream) *s = ws->stream;
+    // allocations outgrown by an earlier call: free them once everything that call enqueued has finished
+    if (!ws->retired.empty() && (!ws->in_flight || hipEventQuery(ws->done) == hipSuccess)) ws->free_retired();
     if (ws->in_flight && ws->last_stream != *s) {
         if (hipStreamWaitEvent(*s, ws->done, 0) != hipSuccess) {
             std::lock_guard<std::mutex> lk(ix->sh.mu);
@@ -592,10 +624,9 @@ static int rec_begin(const pn_index *ix, uint64_t call_id, size_t nq, CallRec **
         (void)hipEventSynchronize(r.done);
         rec_resolve(ix, r);
     }
-    if (!r.done) {
-        HIPCHK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        HIPCHK(hipHostMalloc((void **)&r.h_nflag, 64, hipHostMallocDefault));
-    }
+    // (each resource on its own: a record whose event exists but whose pinned word does not must not be used)
+    if (!r.h_nflag) HIPCHK(hipHostMalloc((void **)&r.h_nflag, 64, hipHostMallocDefault));
+    if (!r.done) HIPCHK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
     if (ix->profile && !r.ev[0])
         for (hipEvent_t &e : r.ev) HIPCHK(hipEventCreate(&e));
     r.nq = nq;
@@ -615,6 +646,20 @@ static int rec_end(const pn_index *ix, CallRec *r, hipStream_t s) {
     if (e != hipSuccess) return fail(PN_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e));
     return PN_OK;
 }
+
+// A record is busy from rec_begin to rec_end; a chunk that fails in between (out of memory, a launch error) must give
+// its slot back, or sixteen failed chunks would leave the handle without records for good.
+struct RecGuard {
+    const pn_index *ix;
+    CallRec *r = nullptr;
+    explicit RecGuard(const pn_index *i) : ix(i) {}
+    ~RecGuard() {
+        if (!r) return;
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        r->busy = false;
+        r->pending = false;
+    }
+};
 
 extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
     if (!ix || !out) return fail(PN_ERR_INVALID, "NULL argument");
@@ -1261,6 +1306,8 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
         const size_t nq_pad = round_up(nqc, (size_t)256);  // query tiles are 64 (exact), 128 (MFMA) or 256 (bf16) rows
         CallRec *rec = nullptr;
         PNCHK(rec_begin(ix, call_id, nqc, &rec));
+        RecGuard rec_guard(ix);
+        rec_guard.r = rec;  // released on every early return below; rec_end takes over on success
         if (rec->prof) HIPCHK(hipEventRecord(rec->ev[2], s));
         PNCHK(ws.w_q.ensure(nq_pad * ix->ld * sizeof(T)));
         T *Qp = (T *)ws.w_q.p;
@@ -1307,6 +1354,7 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
         if (!use_bf16 && !use_mfma)
             PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec, qnorm));
         if (rec->prof) HIPCHK(hipEventRecord(rec->ev[3], s));
+        rec_guard.r = nullptr;
         PNCHK(rec_end(ix, rec, s));
     }
     return PN_OK;
@@ -1983,8 +2031,14 @@ extern "C" int pn_pairwise_f64(const double *x, size_t n, size_t cols, ptrdiff_t
 // ---------------------------------------------------------------------------
 static int tree_of(const pn_index *ix, const HostTree **out) {
     if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
-    std::lock_guard<std::mutex> lk(ix->sh.mu);
-    if (!ix->sh.tree) {
+    HostTree *t = ix->sh.tree.load(std::memory_order_acquire);
+    if (!t) {
+        std::lock_guard<std::mutex> lk(ix->sh.tree_mu);  // builders only: queries never take this mutex
+        t = ix->sh.tree.load(std::memory_order_acquire);
+        if (t) {
+            *out = t;
+            return PN_OK;
+        }
         DeviceGuard g(ix->device);
         if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
         const size_t eb = (size_t)ix->elem_bytes, cols = ix->dim ? ix->dim : 1;
@@ -1996,10 +2050,13 @@ static int tree_of(const pn_index *ix, const HostTree **out) {
         }
         if (ix->dim)  // the index's own zero-padded copy of the points, rows back to their unpadded length
             HIPCHK(hipMemcpy2D(host.data(), ix->dim * eb, ix->d_pts, ix->ld * eb, ix->dim * eb, ix->n, hipMemcpyDeviceToHost));
-        ix->sh.tree = host_tree_build(host.data(), ix->n, ix->dim, ix->elem_bytes);
-        if (!ix->sh.tree) return fail(PN_ERR_NOMEM, "ball tree of %zu points: out of memory", ix->n);
+        // BallTree::new(points, metric): the tree's radii and node bounds are the index's metric's (Cosine indexes
+        // included -- src/ball_tree.rs:445-461 passes `metric` to Node::init)
+        t = host_tree_build(host.data(), ix->n, ix->dim, ix->elem_bytes, ix->metric);
+        if (!t) return fail(PN_ERR_NOMEM, "ball tree of %zu points: out of memory", ix->n);
+        ix->sh.tree.store(t, std::memory_order_release);
     }
-    *out = ix->sh.tree;
+    *out = t;
     return PN_OK;
 }
 static int tree_node(const pn_index *ix, uint64_t node, const HostTree **t) {
@@ -2100,7 +2157,9 @@ extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!d_idx_parts || !d_dist_parts || !d_idx_out || !d_dist_out) return fail(PN_ERR_INVALID, "NULL argument");
     if (n_parts == 0 || k_part == 0) return fail(PN_ERR_INVALID, "empty parts");
-    if (n_parts * k_part * 12 > 64 * 1024) return fail(PN_ERR_UNSUPPORTED, "n_parts * k_part too large for one merge");
+    if (n_parts > 0x7FFFFFFFull || k_part > 0x7FFFFFFFull || k_out > 0x7FFFFFFFull || nq > 0x7FFFFFFFull)
+        return fail(PN_ERR_UNSUPPORTED, "merge sizes beyond 2^31");
+    // (any n_parts x k_part: beyond 64 KiB of LDS the merge ranks by binary search over the sorted parts, select.hip)
     PNCHK(check_device(device));
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);

@@ -237,7 +237,8 @@ hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size
 // ---- tree.cpp: the reference's ball tree, built on the host only when its introspection API is used
 namespace pn {
 struct HostTree;
-HostTree *host_tree_build(const void *pts, size_t n, size_t dim, int elem_bytes);  // nullptr: out of memory
+// metric: 0 Euclidean, 1 Cosine (Node::init and node_distance_lower_bound use the tree's metric, src/ball_tree.rs:309, 459)
+HostTree *host_tree_build(const void *pts, size_t n, size_t dim, int elem_bytes, int metric);  // nullptr: out of memory
 void host_tree_free(HostTree *h);
 size_t host_tree_num_nodes(const HostTree *h);
 const uint64_t *host_tree_idx(const HostTree *h);

@@ -662,11 +662,75 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     }
 }
 
+// The same merge for ANY n_parts x k_part (no LDS residency): every part is ascending in (key, index) with its absent
+// slots last -- what every query entry point and this merge itself produce -- so the rank of an entry in the union is
+// its position in its own part plus, for every other part, the number of that part's entries below it: one binary
+// search per (entry, other part), all reads served by L2.  One wave per query; only the first k_out entries of a part
+// can reach the output.  (BallTree::query has no limit on k, src/ball_tree.rs:102-121: the sharded k-NN must not
+// inherit one from a kernel's LDS budget -- 8 GPUs x k = 1000 is 96 KB of (key, index) pairs.)
+__global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *__restrict__ idx_parts,
+                                                               const float *__restrict__ dist_parts, int n_parts,
+                                                               size_t idx_part_stride, size_t dist_part_stride,
+                                                               int nq, int k_part, int k_out,
+                                                               uint64_t *__restrict__ idx_out,
+                                                               float *__restrict__ dist_out,
+                                                               const uint32_t *__restrict__ nq_dev) {
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    if (nq_dev && q >= (size_t)*nq_dev) return;
+    const uint32_t kp = (uint32_t)k_part, ko = (uint32_t)k_out;
+    const uint32_t lim = kp < ko ? kp : ko;  // positions of a part that can reach the output
+    uint32_t n_valid = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        const uint64_t *pi = idx_parts + (size_t)p * idx_part_stride + q * kp;
+        const float *pd = dist_parts + (size_t)p * dist_part_stride + q * kp;
+        // valid entries of this part (absent slots are a suffix): binary search for the first absent one
+        uint32_t lo = 0, hi = kp;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pi[mid] != ~0ull) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t nv = lo;
+        n_valid += nv;
+        for (uint32_t j = (uint32_t)lane; j < (nv < lim ? nv : lim); j += 64) {
+            const uint64_t ix = pi[j];
+            const uint32_t key = sel_key(pd[j]);
+            uint32_t rank = j;
+            for (int o = 0; o < n_parts && rank < ko; ++o) {
+                if (o == p) continue;
+                const uint64_t *oi = idx_parts + (size_t)o * idx_part_stride + q * kp;
+                const float *od = dist_parts + (size_t)o * dist_part_stride + q * kp;
+                uint32_t a = 0, b = kp;  // first entry of part o that is absent or not below (key, ix)
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    const uint64_t mi = oi[mid];
+                    const uint32_t mk = sel_key(od[mid]);
+                    const bool below = mi != ~0ull && (mk < key || (mk == key && mi < ix));
+                    if (below) a = mid + 1; else b = mid;
+                }
+                rank += a;
+            }
+            if (rank < ko) {
+                idx_out[q * ko + rank] = ix;
+                dist_out[q * ko + rank] = key_to_dist(key);
+            }
+        }
+    }
+    for (uint32_t r = n_valid + (uint32_t)lane; r < ko; r += 64) {  // absent tail
+        idx_out[q * ko + r] = ~0ull;
+        dist_out[q * ko + r] = key_to_dist(KeyOf<float>::kNaN);
+    }
+}
+
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev) {
     const size_t sh = (size_t)n_parts * k_part * 12;
-    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    if (sh > 64 * 1024) {  // beyond the LDS-resident merge: the rank-by-binary-search merge of sorted parts
+        hipLaunchKernelGGL(merge_sorted_topk_kernel, dim3((unsigned)nq), dim3(64), 0, s, idx_parts, dist_parts, n_parts,
+                           idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
                        idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev);
     return hipGetLastError();

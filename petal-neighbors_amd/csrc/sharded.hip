@@ -123,12 +123,26 @@ static_assert(sizeof(ncclUniqueId) == PN_COMM_ID_BYTES, "PN_COMM_ID_BYTES must b
 namespace {
 constexpr size_t kShardChunk = 131072;  // queries per exchange when a batch is cut (two chunks in flight)
 
+// grows only; an outgrown allocation may still be read by kernels of an asynchronous call that has already returned,
+// so it is retired to its GPU's list and freed once that GPU's end-of-use event has passed (acquire_dev), never with a
+// hipFree (a device-wide wait) inside an "enqueue and return" call
 struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
+    std::vector<void *> *retired = nullptr;
     int ensure(size_t need) {
         if (need <= bytes && p) return PN_OK;
-        if (p) (void)hipFree(p);
+        if (p) {
+            bool kept = false;
+            if (retired) {
+                try {
+                    retired->push_back(p);
+                    kept = true;
+                } catch (const std::bad_alloc &) {
+                }
+            }
+            if (!kept) (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
         const size_t want = need + need / 8 + 256;
@@ -158,6 +172,23 @@ struct Dev {  // one GPU this process drives = one rank of the communicator
     hipEvent_t ev_local[2] = {nullptr, nullptr}, ev_merged[2] = {nullptr, nullptr}, ev_done = nullptr;
     std::vector<int> parts;
     Buf q, out_idx, out_dist, lparts, pack[2], gathered[2], rad_a, rad_b;
+    // End of the last call that used this GPU's exchange buffers (pack / gathered / lparts) and the stream it was
+    // enqueued on: the device entry point returns while its kernels run, so a later call on ANOTHER stream is ordered
+    // behind this event before it touches the buffers (`mu` only serialises the enqueueing).  Same scheme as
+    // Workspace::done in index.hip.
+    hipEvent_t ev_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool in_flight = false;
+    std::vector<void *> retired;
+    // (Bufs point at this Dev's retired list: adopt() after the vector of Devs has its final size)
+    void adopt() {
+        Buf *bs[] = {&q, &out_idx, &out_dist, &lparts, &pack[0], &pack[1], &gathered[0], &gathered[1], &rad_a, &rad_b};
+        for (Buf *b : bs) b->retired = &retired;
+    }
+    void free_retired() {
+        for (void *r : retired) (void)hipFree(r);
+        retired.clear();
+    }
 };
 struct SetGuard {
     int prev = -1;
@@ -206,7 +237,8 @@ static void destroy_dev(Dev &d) {
     Buf *bufs[] = {&d.q, &d.out_idx, &d.out_dist, &d.lparts, &d.pack[0], &d.pack[1], &d.gathered[0], &d.gathered[1],
                    &d.rad_a, &d.rad_b};
     for (Buf *b : bufs) b->release();
-    hipEvent_t evs[] = {d.ev_local[0], d.ev_local[1], d.ev_merged[0], d.ev_merged[1], d.ev_done};
+    d.free_retired();
+    hipEvent_t evs[] = {d.ev_local[0], d.ev_local[1], d.ev_merged[0], d.ev_merged[1], d.ev_done, d.ev_use};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -231,6 +263,7 @@ static int init_dev_resources(Dev &d) {
         SHIP(hipEventCreateWithFlags(&d.ev_merged[i], hipEventDisableTiming));
     }
     SHIP(hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
+    SHIP(hipEventCreateWithFlags(&d.ev_use, hipEventDisableTiming));
     return PN_OK;
 }
 
@@ -265,6 +298,7 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
         if (std::find(distinct.begin(), distinct.end(), devices[i]) == distinct.end()) distinct.push_back(devices[i]);
     sh->world = (int)distinct.size();
     sh->devs.resize(distinct.size());
+    for (Dev &d : sh->devs) d.adopt();
     int rc = PN_OK;
     for (size_t r = 0; r < distinct.size() && rc == PN_OK; ++r) {
         sh->devs[r].device = distinct[r];
@@ -331,6 +365,7 @@ extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_l
     sh->per = per;
     sh->rank_mode = true;
     sh->devs.resize(1);
+    sh->devs[0].adopt();
     sh->devs[0].device = device;
     sh->devs[0].comm_rank = rank;
     int rc = init_dev_resources(sh->devs[0]);
@@ -466,6 +501,23 @@ static size_t k_dev_of(const pn_sharded *sh, size_t k) {  // slots per query a G
     return (size_t)std::min<uint64_t>(k, most ? most : 1);
 }
 
+// A call that is about to use d's exchange buffers on stream `s`: ordered behind the previous call's end when that
+// ran on another stream; allocations outgrown by earlier calls are freed once that end has passed.
+static int acquire_dev(Dev &d, hipStream_t s) {
+    if (!d.retired.empty() && (!d.in_flight || hipEventQuery(d.ev_use) == hipSuccess)) d.free_retired();
+    if (d.in_flight && d.last_stream != s) SHIP(hipStreamWaitEvent(s, d.ev_use, 0));
+    return PN_OK;
+}
+struct DevUse {
+    Dev &d;
+    hipStream_t s;
+    ~DevUse() {
+        d.in_flight = hipEventRecord(d.ev_use, s) == hipSuccess;
+        if (!d.in_flight) (void)hipStreamSynchronize(s);  // cannot mark the end of the call: wait for it instead
+        d.last_stream = s;
+    }
+};
+
 // rank mode (or one GPU): queries and results on this process's GPU, everything enqueued on `s`
 static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
                             size_t k, uint64_t *d_idx, float *d_dist, hipStream_t s) {
@@ -474,8 +526,11 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
     if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
     if (sh->n_shards == 1 && !sh->exchange_always)  // one shard: nothing to exchange, straight into the caller's buffers
         return query_device_strided_f32(sh->parts[0].ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, k_out, s);
+    // the merges' LDS-free fallback serves any world x k (select.hip), so nothing here is bounded by k
     const size_t chunk = nq > kShardChunk ? kShardChunk : nq;
     const bool overlapped = nq > chunk;  // two chunks in flight: exchange + merge on the second stream
+    SPN(acquire_dev(d, s));
+    DevUse in_use{d, s};  // records the end-of-use event on every return path
     int set = 0;
     size_t n_chunks = 0;
     for (size_t q0 = 0; q0 < nq; q0 += chunk, set ^= 1, ++n_chunks) {

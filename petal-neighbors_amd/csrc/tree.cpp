@@ -6,7 +6,7 @@
 // accessors is called.  Then the index builds -- once, on the host, from its own copy of the points -- the same
 // implicit complete binary tree the reference builds (src/ball_tree.rs:38-63, 445-461, 504-613): children of node i
 // are 2i+1 and 2i+2, every node holds a range of the permutation `idx`, its centroid (sequential mean) and radius
-// (largest distance to the centroid), split at the median of the column of maximum spread by a Lomuto quick-select
+// (largest distance to the centroid under the tree's OWN metric -- Euclidean or Cosine, Node::init takes `metric`), split at the median of the column of maximum spread by a Lomuto quick-select
 // whose pivot is the range's last element.  Same arithmetic, same order, same tie rules, so node for node the
 // answers equal the reference's.  Compiled with -ffp-contract=off (no fused multiply-add anywhere: the reference's
 // folds are separately rounded, src/distance.rs:26-35).
@@ -47,9 +47,23 @@ inline T euclid(const T *a, const T *b, size_t dim) {
     return t_sqrt<T>(s);
 }
 
+// Cosine::distance (src/distance.rs:86-107): three sequential sums (products and additions separately rounded),
+// 1 - dot / (sqrt(sum a^2) * sqrt(sum b^2)); both vectors have the tree's dimension here
+template <typename T>
+inline T cosine(const T *a, const T *b, size_t dim) {
+    T dot = (T)0, n1 = (T)0, n2 = (T)0;
+    for (size_t k = 0; k < dim; ++k) dot = dot + a[k] * b[k];
+    for (size_t k = 0; k < dim; ++k) n1 = n1 + a[k] * a[k];
+    for (size_t k = 0; k < dim; ++k) n2 = n2 + b[k] * b[k];
+    return (T)1 - dot / (t_sqrt<T>(n1) * t_sqrt<T>(n2));
+}
+
 template <typename T>
 struct Tree {
     size_t n = 0, dim = 0;
+    int metric = 0;  // BallTree::metric (src/ball_tree.rs:23): 0 Euclidean, 1 Cosine
+    // metric.distance: Node::init and node_distance_lower_bound go through it (src/ball_tree.rs:309, 459)
+    T dist(const T *a, const T *b) const { return metric == 1 ? cosine<T>(a, b, dim) : euclid<T>(a, b, dim); }
     const T *pts = nullptr;  // [n][dim], owned by `store`
     std::vector<T> store;
     std::vector<uint64_t> idx;                // the permutation (BallTree::idx, src/ball_tree.rs:21)
@@ -71,7 +85,7 @@ struct Tree {
         const T len = (T)(e - s);
         for (size_t k = 0; k < dim; ++k) c[k] /= len;
         T mx = (T)0;
-        for (size_t j = s; j < e; ++j) mx = t_max<T>(euclid<T>(c, row(idx[j]), dim), mx);
+        for (size_t j = s; j < e; ++j) mx = t_max<T>(dist(c, row(idx[j])), mx);
         radius[node] = mx;
         start[node] = s;
         end[node] = e;
@@ -151,9 +165,10 @@ struct HostTree {
 };
 
 template <typename T>
-static bool build_into(Tree<T> &t, const void *pts, size_t n, size_t dim) {
+static bool build_into(Tree<T> &t, const void *pts, size_t n, size_t dim, int metric) {
     t.n = n;
     t.dim = dim;
+    t.metric = metric;
     const T *p = static_cast<const T *>(pts);
     t.store.assign(p, p + n * dim);
     t.pts = t.store.data();
@@ -172,16 +187,16 @@ static bool build_into(Tree<T> &t, const void *pts, size_t n, size_t dim) {
     return true;
 }
 
-HostTree *host_tree_build(const void *pts, size_t n, size_t dim, int elem_bytes) {
+HostTree *host_tree_build(const void *pts, size_t n, size_t dim, int elem_bytes, int metric) {
     if (n == 0 || (dim == 0 && n >= 2)) return nullptr;  // rejected at index creation already
     HostTree *h = new (std::nothrow) HostTree();
     if (!h) return nullptr;
     h->elem_bytes = elem_bytes;
     try {
         if (elem_bytes == 4)
-            build_into<float>(h->f, pts, n, dim);
+            build_into<float>(h->f, pts, n, dim, metric);
         else
-            build_into<double>(h->d, pts, n, dim);
+            build_into<double>(h->d, pts, n, dim, metric);
     } catch (const std::bad_alloc &) {
         delete h;
         return nullptr;
@@ -221,17 +236,16 @@ int host_tree_compare(const HostTree *h, size_t x, size_t y) {
     if (a == b) return 0;
     return 2;
 }
-// node_distance_lower_bound (src/ball_tree.rs:303-318): max(|c1 - c2| - R1 - R2, 0), evaluated left to right in T
+// node_distance_lower_bound (src/ball_tree.rs:303-318): max(metric.distance(c1, c2) - R1 - R2, 0), evaluated left to right
+// in T (`lb < 0 ? 0 : lb`: a NaN stays NaN, as in the reference)
 double host_tree_lower_bound(const HostTree *h, size_t n1, size_t n2) {
     if (h->elem_bytes == 4) {
         const Tree<float> &t = h->f;
-        const float lb = euclid<float>(t.centroid.data() + n1 * t.dim, t.centroid.data() + n2 * t.dim, t.dim) -
-                         t.radius[n1] - t.radius[n2];
+        const float lb = t.dist(t.centroid.data() + n1 * t.dim, t.centroid.data() + n2 * t.dim) - t.radius[n1] - t.radius[n2];
         return (double)(lb < 0.0f ? 0.0f : lb);
     }
     const Tree<double> &t = h->d;
-    const double lb = euclid<double>(t.centroid.data() + n1 * t.dim, t.centroid.data() + n2 * t.dim, t.dim) -
-                      t.radius[n1] - t.radius[n2];
+    const double lb = t.dist(t.centroid.data() + n1 * t.dim, t.centroid.data() + n2 * t.dim) - t.radius[n1] - t.radius[n2];
     return lb < 0.0 ? 0.0 : lb;
 }
 
