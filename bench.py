@@ -256,6 +256,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
     ap.add_argument("--structure", type=int, default=0, help="PN_OPT_MFMA_STRUCTURE; 0 = auto")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity leg (outside the timed region)")
+    ap.add_argument("--shared-thresholds", type=int, default=-1,
+                    help="PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto (library default), >= 2 the rank itself")
     ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
                     help="abi: the all-gather is RCCL behind the C ABI (pn_sharded_*); torch: torch.distributed")
     args = ap.parse_args()
@@ -343,6 +345,8 @@ def main():
             tree.set_option(_lib.PN_OPT_FILTER_SLOTS, args.slots)
         if args.structure:
             tree.set_option(_lib.PN_OPT_MFMA_STRUCTURE, args.structure)
+        if args.shared_thresholds >= 0:
+            tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, args.shared_thresholds)
         tree.set_option(_lib.PN_OPT_PROFILE, 1)
     n_local = index.n_local
     out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device=dev)

@@ -85,9 +85,14 @@ enum {
     PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
     PN_OPT_MFMA_STRUCTURE = 6, /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
                                  buffers, 1 workgroup/CU; 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU */
-    PN_OPT_EXCHANGE_ALWAYS = 7 /* pn_sharded_set_option only.  A handle with ONE shard answers straight into the
+    PN_OPT_EXCHANGE_ALWAYS = 7, /* pn_sharded_set_option only.  A handle with ONE shard answers straight into the
                                   caller's buffers (nothing to exchange); 1 sends it through the packed buffer, the
                                   all-gather and the merge all the same (tests: RCCL at world size 1) */
+    PN_OPT_SHARED_THRESHOLDS = 8 /* bf16 tier, plans with several row segments per query: 1 (default) = the segments
+                                  of a query tighten each other's thresholds while the filter runs (refresher
+                                  workgroups in the idle workgroup slots); 0 = off; n >= 2 = on with the shared
+                                  threshold at the n-th smallest bound of the union (experiments).  Never changes a
+                                  result: only how many candidates the filter keeps. */
 };
 
 typedef struct pn_index pn_index;

@@ -19,6 +19,7 @@ PN_ENGINE_AUTO, PN_ENGINE_EXACT, PN_ENGINE_MFMA, PN_ENGINE_BF16 = 0, 1, 2, 3
 PN_OPT_ENGINE, PN_OPT_SEGMENTS, PN_OPT_INDEX_BASE, PN_OPT_PROFILE, PN_OPT_FILTER_SLOTS = 1, 2, 3, 4, 5
 PN_OPT_MFMA_STRUCTURE = 6
 PN_OPT_EXCHANGE_ALWAYS = 7
+PN_OPT_SHARED_THRESHOLDS = 8
 
 
 class PnInfo(C.Structure):

@@ -63,7 +63,7 @@ typedef __attribute__((address_space(3))) void lds_void_b;
 typedef const __attribute__((address_space(1))) void glb_void_b;
 
 #ifdef PN_DIAG_BF_COUNT  // diagnostic build only: event counters
-__device__ unsigned long long g_bfdbg[12];
+__device__ unsigned long long g_bfdbg[16];  // 12.. refreshers: query visits, updates, passes, rejected reads
 // per-wave accumulators in registers (dbg_), flushed by one atomic per counter at the end of a run: an atomic per
 // event would itself be what the barrier waits for
 #define BF_COUNT(i, v) (dbg_[i] += (unsigned long long)(v))
@@ -445,17 +445,19 @@ __device__ __forceinline__ void bf_compact_load(const uint2 *ce, uint32_t n, int
         ix[m] = e.y;
     }
 }
-template <int M>
+__device__ __forceinline__ void sh_store_entry(uint2 *p, uint32_t key, uint32_t row);
+// WT: the kept entries are rewritten write-through (shared thresholds: other XCDs read them from memory)
+template <int M, bool WT = false>
 __device__ __forceinline__ void bf_compact_finish(uint2 *ce, const uint32_t (&key)[M], const uint32_t (&ix)[M],
                                                   uint32_t n, uint32_t kp, int lane, uint32_t &T_out, uint32_t &n_out);
-template <int M>
+template <int M, bool WT = false>
 __device__ __forceinline__ void bf_compact(uint2 *ce, uint32_t n, uint32_t kp, int lane, uint32_t &T_out,
                                            uint32_t &n_out) {
     uint32_t key[M], ix[M];
     bf_compact_load<M>(ce, n, lane, key, ix);
-    bf_compact_finish<M>(ce, key, ix, n, kp, lane, T_out, n_out);
+    bf_compact_finish<M, WT>(ce, key, ix, n, kp, lane, T_out, n_out);
 }
-template <int M>
+template <int M, bool WT>
 __device__ __forceinline__ void bf_compact_finish(uint2 *ce, const uint32_t (&key)[M], const uint32_t (&ix)[M],
                                                   uint32_t n, uint32_t kp, int lane, uint32_t &T_out, uint32_t &n_out) {
     bool valid[M];
@@ -497,7 +499,10 @@ __device__ __forceinline__ void bf_compact_finish(uint2 *ce, const uint32_t (&ke
     for (int m = 0; m < M; ++m) {
         const bool keep = sel[m] || (eq[m] && ix[m] <= row_cut);
         const unsigned long long mask = __ballot(keep);
-        if (keep) ce[pos + (uint32_t)__popcll(mask & lt)] = make_uint2(key[m], ix[m]);
+        if (keep) {
+            if (WT) sh_store_entry(ce + pos + (uint32_t)__popcll(mask & lt), key[m], ix[m]);
+            else ce[pos + (uint32_t)__popcll(mask & lt)] = make_uint2(key[m], ix[m]);
+        }
         pos += (uint32_t)__popcll(mask);
     }
     T_out = T;
@@ -754,6 +759,134 @@ __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA],
     c = nc;
 }
 
+// ---------------------------------------------------------------------------
+// Shared thresholds (SH): the segments of a query tighten each other's thresholds DURING the run.
+//
+// A segment's buffer of a k = 10 call takes ~19 appends into 64 slots, never compacts inside the run, and so its
+// threshold stays where the scout's seed put it (the 2.4e-4 quantile) while ~24 rows per query matter: the seed, not k',
+// sets the appends -- and every append is a rare-path entry that the whole workgroup waits for at the tile barrier.
+// What the segments of a query hold TOGETHER says much more: the r-th smallest bound over the union of their buffers
+// is an upper bound of the r-th smallest bound of the whole corpus (the r-th smallest of any subset is), so with
+// r > (rows whose bound lies below the k-th neighbour's distance) it is a valid threshold for every segment -- and the
+// proof in select.hip does not even need that: rows are only ever dropped against the threshold finally reported.
+//  * main workgroups store their entries write-through (sc1) and, every kShPeriod tiles, publish their fill counts
+//    (word = epoch | tile tag | count, sc1) after a vmcnt(0): what a published count covers has reached memory;
+//  * REFRESHER workgroups -- the grid's last blocks, in the workgroup slots the aligned partition leaves idle (C2: 480
+//    of 512) -- loop over the queries: read the segments' words, gather the keys (sc1 loads: the writers sit on other
+//    XCDs, whose L2 is not coherent with this one), re-read the words (a word that changed means a buffer may have
+//    been rewritten meanwhile: skip), radix-select the r-th smallest in registers, atomicMin it into the query's
+//    shared threshold word (the seed array the run started from);
+//  * main waves re-read their queries' shared words at the same cadence (issued behind the LDS-DMA, consumed a tile
+//    later: nothing waits) and lower their thresholds.
+// Nothing waits for another workgroup: a refresher that never runs, runs late or reads stale words only leaves the
+// thresholds where they were.  Refreshers leave when every main workgroup has counted itself done (or after a bounded
+// number of passes).  Racy or stale reads cannot make an answer wrong -- at worst a threshold drops below the k-th
+// neighbour's bound and the query goes to the next tier.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kShPeriod = 32;      // tiles between two publish / re-read points of a main wave
+constexpr uint32_t kShMaxPass = 1u << 14;  // a refresher's pass limit (termination does not depend on the mains)
+__device__ __forceinline__ uint32_t sh_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sh_store(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sh_store_entry(uint2 *p, uint32_t key, uint32_t row) {  // one 8-byte write-through store
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)row << 32) | key, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// published word: [31:20] epoch of the launch (1 .. 4095), [19:12] tag = the publishing wave's compaction count so far
+// (mod 256): words of one launch with equal tags describe one append-only history of the buffer; [11:0] count
+__device__ __forceinline__ uint32_t sh_tag(uint32_t epoch, uint32_t ncomp) { return (epoch << 20) | ((ncomp & 0xFFu) << 12); }
+
+template <int M>
+__device__ __forceinline__ void bf_refresher(const uint2 *__restrict__ cand, const uint32_t *pcnt, uint32_t *gtau,
+                                          const uint32_t *done, uint32_t n_main, size_t nq_pad, uint32_t nseg,
+                                          uint32_t epoch, uint32_t rank, uint32_t wv, uint32_t n_wv, int lane) {
+    constexpr uint32_t CAP = 64u * M;
+    constexpr int NK = 8;  // keys per lane: up to 512 entries of a query's union (more: the first 512, a subset)
+    // lanes 0 .. nseg-1: the segments' published words of a query; lane 63: the mains' done counter
+    auto words_of = [&](size_t q) -> uint32_t {
+        uint32_t x = 0;
+        if (lane < (int)nseg) x = sh_load(pcnt + (size_t)lane * nq_pad + q);
+        else if (lane == 63) x = sh_load(done);
+        return x;
+    };
+    for (uint32_t pass = 0; pass < kShMaxPass; ++pass) {
+        uint32_t x_next = words_of(wv < nq_pad ? wv : 0);
+        for (size_t q = wv; q < nq_pad; q += n_wv) {
+            const uint32_t x = x_next;
+            x_next = words_of(q + n_wv < nq_pad ? q + n_wv : q);  // the next query's words travel while this one is merged
+            if ((uint32_t)__builtin_amdgcn_readlane((int)x, 63) >= n_main) return;
+#ifdef PN_DIAG_BF_COUNT
+            if (lane == 0) atomicAdd(&g_bfdbg[12], 1ull);
+#endif
+            uint32_t c = (lane < (int)nseg && (x >> 20) == epoch) ? (x & 0xFFFu) : 0u;
+            if (c > CAP) c = 0;
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
+                if (lane >= d) inc += t;
+            }
+            uint32_t U = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (U < rank) continue;
+            if (U > 64u * NK) U = 64u * NK;
+            const uint32_t excl = inc - c;
+            uint32_t key[NK];
+#pragma unroll
+            for (int i = 0; i < NK; ++i) key[i] = 0xFFFFFFFFu;
+            const int nk = (int)((U + 63u) / 64u);  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                if (i < nk) {
+                    const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
+                    uint32_t sg = 0, pos = 0;
+                    for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
+                        const uint32_t os = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)sgi);
+                        const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)sgi);
+                        if (e >= os && e < os + cs) {
+                            sg = sgi;
+                            pos = e - os;
+                        }
+                    }
+                    if (e < U) key[i] = sh_load(&cand[((size_t)sg * nq_pad + q) * CAP + pos].x);
+                }
+            }
+            // A buffer is append-only between two compactions of its wave, and a compaction first publishes the buffer
+            // as empty under a new tag: if the word read again now has the same epoch and tag and no smaller count, the
+            // c entries read in between were not rewritten.  Otherwise skip the query this pass.
+            uint32_t x2 = x;
+            if (lane < (int)nseg) x2 = sh_load(pcnt + (size_t)lane * nq_pad + q);
+            if (__any(lane < (int)nseg && c != 0u && ((x2 >> 12) != (x >> 12) || (x2 & 0xFFFu) < c))) {
+#ifdef PN_DIAG_BF_COUNT
+                if (lane == 0) atomicAdd(&g_bfdbg[15], 1ull);
+#endif
+                continue;
+            }
+#ifdef PN_DIAG_BF_COUNT
+            if (lane == 0) atomicAdd(&g_bfdbg[13], 1ull);
+#endif
+            uint32_t T = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cnd = T | (1u << bit);
+                uint32_t n_lt = 0;
+#pragma unroll
+                for (int i = 0; i < NK; ++i)
+                    if (i < nk) n_lt += (uint32_t)__popcll(__ballot(key[i] < cnd));
+                if (n_lt < rank) T = cnd;
+            }
+            // T = the rank-th smallest key; rows with a bound EQUAL to it must still pass the strict '<': T + 1
+            if (lane == 0 && T < 0xFFFFFFFEu)
+                (void)__hip_atomic_fetch_min(gtau + q, T + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#ifdef PN_DIAG_BF_COUNT
+        if (lane == 0) atomicAdd(&g_bfdbg[14], 1ull);
+#endif
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // append this lane's survivors of one (32-row block, query block) and compact the buffers that filled up.
 // cnt is the fill count of the lane's query (identical in lanes j and j+32, which hold different rows).
 // ns counts the vector-memory instructions this wave has issued since its last LDS-DMA (wave-uniform): the
@@ -765,10 +898,14 @@ __device__ __forceinline__ void bf_chain_p(const char *arow, bf16x8 (&pre)[kLA],
 // RAD (radius queries): the threshold is the query's fixed radius bound and every row below it must be kept, so
 // a buffer that would need compacting is marked overflowed instead (count > capacity; the host re-runs the call
 // on the exact engine) and its threshold drops to -inf so that nothing more is stored.
-template <int M, bool RAD, bool TAGGED = false>
+// SH (shared thresholds, above): entries are stored write-through, and a buffer about to be compacted is first
+// published as empty under the wave's next tag (pc_blk = the published words of this query block's 32 buffers, pc_tag =
+// epoch | the wave's compaction count, advanced here).
+template <int M, bool RAD, bool TAGGED = false, bool SH = false>
 __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau, uint32_t &cnt, uint32_t row0, int h,
                                         int jq, int lane, uint32_t kp, uint2 *ceq, uint2 *ce_blk,
-                                        uint32_t &ns BF_DBG_ARG) {
+                                        uint32_t &ns BF_DBG_ARG, uint32_t *pc_blk = nullptr, uint32_t *pc_ncomp = nullptr,
+                                        uint32_t pc_epoch = 0) {
 #ifdef PN_DIAG_BF_NOSLOW  // timing-only build: results are wrong
     asm volatile("" ::"v"(acc[0]), "v"(tau));
 #ifdef PN_DIAG_BF_FAKESLOW
@@ -851,7 +988,8 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
 #ifdef PN_DIAG_BF_NOSTORE  // timing-only: everything but the store instruction
             asm volatile("" ::"v"(o), "v"(f2s(mn)), "v"(rowb + (ridx & 3u) + 8u * (ridx >> 2)));
 #else
-            ceq[o] = make_uint2(f2s(mn), rowb + (ridx & 3u) + 8u * (ridx >> 2));
+            if (SH) sh_store_entry(ceq + o, f2s(mn), rowb + (ridx & 3u) + 8u * (ridx >> 2));
+            else ceq[o] = make_uint2(f2s(mn), rowb + (ridx & 3u) + 8u * (ridx >> 2));
 #endif
         }
         BF_COUNT(1, __popcll(seen));
@@ -871,7 +1009,8 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
             if (p) {
                 const uint32_t o = cnt + (h ? other : 0u);  // half 0 writes first
                 // C/D map of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 h
-                ceq[o] = make_uint2(f2s(v), rowb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                if (SH) sh_store_entry(ceq + o, f2s(v), rowb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                else ceq[o] = make_uint2(f2s(v), rowb + (uint32_t)((r & 3) + 8 * (r >> 2)));
             }
             BF_COUNT(1, __popcll(__ballot(p)));
             cnt += pp + other;
@@ -891,6 +1030,10 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
 #ifdef PN_DIAG_BF_COUNT
         tc_ = bf_stamp();
 #endif
+        if (SH) {  // the buffers about to be rewritten read "empty" to the refreshers from here to the next publish
+            *pc_ncomp += 1u;
+            if (h == 0 && ((need >> jq) & 1ull)) sh_store(pc_blk + jq, sh_tag(pc_epoch, *pc_ncomp));
+        }
         // the entries were stored by both halves of the wave: they must have left before they are read back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ns = 0;
@@ -900,7 +1043,7 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
             uint32_t T, nn;
             BF_COUNT(2, 1);
-            bf_compact<M>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
+            bf_compact<M, SH>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
             if (jq == j) {
                 tau = s2f(T);
                 cnt = nn;
@@ -1008,7 +1151,17 @@ __device__ __forceinline__ void bf_wait_dma(uint32_t ns) {
 // MODE 0: a run may scout for itself, then filters (plans without a shared scout); 1: scout-only launch (scout_out
 // given, no buffers touched); 2: filter with the thresholds in tau_init (no scout code: the scout pass's lists and
 // accumulators would otherwise set the kernel's register count, and main-loop values would live in scratch).
-template <int KS, int M, bool RAD, bool CI, int MODE, bool CAPT>
+// SH (MODE 2 only): shared thresholds -- the first n_main blocks are the main workgroups, the rest refreshers; sh =
+// {pcnt, done, epoch, rank} (see "Shared thresholds" above); tau_init is then also the array of shared words.
+struct BfShared {
+    uint32_t *pcnt;   // published fill counts [nseg][nq_pad]
+    uint32_t *done;   // main workgroups that have finished (zeroed by the host before the launch)
+    uint32_t n_main;  // main workgroups (the grid has more blocks: the refreshers)
+    uint32_t epoch;   // 1 .. 4095, different from the previous launch on these buffers
+    uint32_t rank;    // r: the shared threshold is the r-th smallest bound of the union
+    uint32_t nseg;    // segments per query
+};
+template <int KS, int M, bool RAD, bool CI, int MODE, bool CAPT, bool SH = false>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
                                                              uint32_t kp, uint2 *__restrict__ cand,
@@ -1016,8 +1169,9 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                                                              uint32_t *__restrict__ ctau, size_t nq_pad,
                                                              uint32_t split, uint32_t seg_per_part,
                                                              uint32_t scout_max,
-                                                             const uint32_t *__restrict__ tau_init,
-                                                             float *__restrict__ scout_out) {
+                                                             const uint32_t *tau_init,
+                                                             float *__restrict__ scout_out, BfShared sh) {
+    static_assert(!SH || (MODE == 2 && !RAD && !CAPT), "shared thresholds: main pass of a k-NN call only");
     constexpr int C = 2 * KS, CP = C + 1;
     constexpr uint32_t CAP = 64u * M;
     constexpr bool TAG = M >= kBfTagFromM;
@@ -1029,6 +1183,12 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jq = lane & 31, h = lane >> 5;
     BF_DBG_DECL;
+    if (SH && blockIdx.x >= sh.n_main) {  // a refresher workgroup: four waves over the queries, until the mains are done
+        const uint32_t n_wv = (gridDim.x - sh.n_main) * 4u, wv = (blockIdx.x - sh.n_main) * 4u + (uint32_t)wave;
+        bf_refresher<M>(cand, sh.pcnt, const_cast<uint32_t *>(tau_init), sh.done, sh.n_main, nq_pad, sh.nseg, sh.epoch,
+                        sh.rank, wv, n_wv, lane);
+        return;
+    }
 
     // Work list: (query tile, row part, tile within the part) in that order; `split` row parts per query tile
     // (1 unless the host wants more, shorter segments per query: see bf16_slots in index.hip), tps tiles each
@@ -1036,7 +1196,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     // [w U / W, (w+1) U / W) and walks it in runs that stay inside one (query tile, part).
     const uint32_t tps = (n_tiles + split - 1) / split;
     const unsigned long long U = (unsigned long long)q_tiles * split * tps;
-    const unsigned long long W = gridDim.x;
+    const unsigned long long W = SH ? sh.n_main : gridDim.x;
     unsigned long long w = blockIdx.x;
 #ifndef PN_DIAG_BF_NOREMAP
     // Which slice a hardware block takes (aligned grids: c = W / q_tiles whole workgroups per query tile, slice
@@ -1134,8 +1294,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         if (t_scout < 4u) t_scout = 0;
         if (MODE == 2 || tau_init) {  // thresholds given by the caller (radius queries, shared seed): no scouting
             t_scout = 0;
-            tau0 = s2f(tau_init[q0 + jq]);
-            tau1 = s2f(tau_init[q0 + 32 + jq]);
+            tau0 = s2f(SH ? sh_load(tau_init + q0 + jq) : tau_init[q0 + jq]);
+            tau1 = s2f(SH ? sh_load(tau_init + q0 + 32 + jq) : tau_init[q0 + 32 + jq]);
         }
 #endif
         if (MODE == 1 || (MODE == 0 && scout_out)) {  // scout-only launch: every run contributes its lists
@@ -1275,8 +1435,14 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         }
         ns = 0;
         int cur = 0;
+        // shared thresholds: this wave's published words / shared words, the values re-read at the last publish point
+        uint32_t *pc_blk0 = SH ? sh.pcnt + cell0 : nullptr, *pc_blk1 = SH ? sh.pcnt + cell0 + 32 : nullptr;
+        const uint32_t *gw0 = tau_init + q0 + jq, *gw1 = gw0 + 32;
+        uint32_t g0 = 0, g1 = 0, sh_ncomp = 0;  // sh_ncomp: this wave's compactions so far (wave-uniform)
+        bool g_pending = false;  // (wave-uniform)
         for (uint32_t rt = rt0; rt < rt1; ++rt) {
             const int nxt = cur == 2 ? 0 : cur + 1, prv = cur == 0 ? 2 : cur - 1;
+            const bool sh_point = SH && ((rt - rt0) % kShPeriod) == kShPeriod - 1;  // (wave-uniform)
             const char *tb = tiles + cur * TB;
             const char *arow0 = tb + (jq * CP + h) * 16;
             const char *arow1 = arow0 + 32 * CP * 16;
@@ -1296,14 +1462,15 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             if (rt == rt0) { m0 = __uint_as_float(0x7F800000u); m1 = m0; }  // nothing precedes the first tile
             if (__any(m0 < tau0 || m1 < tau1)) {
                 const uint32_t row0 = (rt - 1) * kBP + 32;
-                if (__any(m0 < tau0)) bf_slow<M, RAD, TAG>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(m1 < tau1)) bf_slow<M, RAD, TAG>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                if (__any(m0 < tau0)) bf_slow<M, RAD, TAG, SH>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS, pc_blk0, &sh_ncomp, sh.epoch);
+                if (__any(m1 < tau1)) bf_slow<M, RAD, TAG, SH>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS, pc_blk1, &sh_ncomp, sh.epoch);
             }
             // mid-tile barrier
 #if defined(PN_DIAG_BF_COUNT)
             const unsigned long long tb0_ = bf_stamp();
 #endif
 #if !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
+            if (sh_point) ns = 0;  // a publish point: every entry stored so far must have reached memory (vmcnt(0))
             bf_wait_dma(ns);
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1314,9 +1481,28 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #if defined(PN_DIAG_BF_COUNT)
             BF_COUNT(6, bf_stamp() - tb0_);
 #endif
+            if (SH) {
+                if (g_pending) {  // the shared words requested a tile ago (older than everything still in flight)
+                    tau0 = fminf(tau0, s2f(g0));
+                    tau1 = fminf(tau1, s2f(g1));
+                    g_pending = false;
+                }
+            }
             if (rt + 2 < rt1) {
                 dma_tile(rt + 2, prv);
                 ns = 0;
+            }
+            if (SH) {
+                if (sh_point) {  // publish the fill counts (what they cover has landed: vmcnt(0) above), re-read the shared words
+                    if (h == 0) {
+                        sh_store(pc_blk0 + jq, sh_tag(sh.epoch, sh_ncomp) | cnt0);
+                        sh_store(pc_blk1 + jq, sh_tag(sh.epoch, sh_ncomp) | cnt1);
+                    }
+                    g0 = sh_load(gw0);
+                    g1 = sh_load(gw1);
+                    g_pending = true;
+                    ns += 4;
+                }
             }
             const bool last = rt + 1 >= rt1;  // (then the requests below are never used: any valid LDS address)
             const char *ntb = last ? tb : tiles + nxt * TB;
@@ -1334,10 +1520,16 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #endif
             if (__any(p0 < tau0 || p1 < tau1)) {
                 const uint32_t row0 = rt * kBP;
-                if (__any(p0 < tau0)) bf_slow<M, RAD, TAG>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-                if (__any(p1 < tau1)) bf_slow<M, RAD, TAG>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+                if (__any(p0 < tau0)) bf_slow<M, RAD, TAG, SH>(a00, p0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS, pc_blk0, &sh_ncomp, sh.epoch);
+                if (__any(p1 < tau1)) bf_slow<M, RAD, TAG, SH>(a01, p1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS, pc_blk1, &sh_ncomp, sh.epoch);
             }
             cur = nxt;
+        }
+        if (SH) {
+            if (g_pending) {
+                tau0 = fminf(tau0, s2f(g0));
+                tau1 = fminf(tau1, s2f(g1));
+            }
         }
         {  // drain: block 1 of the last tile
             if (TAG) {
@@ -1354,8 +1546,14 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                 m1 = fminf(m1, a11[i]);
             }
             const uint32_t row0 = (rt1 - 1) * kBP + 32;
-            if (__any(m0 < tau0)) bf_slow<M, RAD, TAG>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
-            if (__any(m1 < tau1)) bf_slow<M, RAD, TAG>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+            if (__any(m0 < tau0)) bf_slow<M, RAD, TAG, SH>(a10, m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS, pc_blk0, &sh_ncomp, sh.epoch);
+            if (__any(m1 < tau1)) bf_slow<M, RAD, TAG, SH>(a11, m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS, pc_blk1, &sh_ncomp, sh.epoch);
+            if (SH) {  // the run is over: its buffers are cut below and read "empty" to the refreshers from now on
+                if (h == 0) {
+                    sh_store(pc_blk0 + jq, sh_tag(sh.epoch, sh_ncomp + 1u));
+                    sh_store(pc_blk1 + jq, sh_tag(sh.epoch, sh_ncomp + 1u));
+                }
+            }
         }
         } else {
         // ---- prologue: first tile -> LDS[0]
@@ -1553,6 +1751,10 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #endif
         }
         u0 = run_end;
+    }
+    if (SH) {  // this main workgroup is done: the refreshers leave once all are
+        __syncthreads();
+        if (tid == 0) (void)__hip_atomic_fetch_add(sh.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1908,7 +2110,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
 
 #ifdef PN_DIAG_BF_COUNT
 extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
-    unsigned long long z[12] = {0};
+    unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfdbg), sizeof(z)) != hipSuccess) return 1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_bfdbg), z, sizeof(z)) != hipSuccess) return 1;
     return 0;
@@ -2012,7 +2214,7 @@ constexpr bool kBfCapture = false;
 template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                const uint32_t *tau_init, float *scout_out, hipStream_t s) {
+                                const uint32_t *tau_init, float *scout_out, const Bf16Shared *shp, hipStream_t s) {
     const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16;  // three tile buffers (software-pipelined main loop)
 #define PN_BF_LAUNCH_MODE(MD)                                                                                          \
     {                                                                                                                   \
@@ -2022,7 +2224,25 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         if (e != hipSuccess) return e;                                                                                  \
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,       \
                            static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,           \
-                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out);     \
+                           static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out,      \
+                           BfShared{});                                                                                 \
+    }
+    if (shp) {  // shared thresholds: main pass with refresher workgroups behind the n_wg main ones
+        if constexpr (!RAD && M <= 2 && !kBfCapture) {
+            if (!tau_init || scout_out || split != 1 || shp->n_refresh < 1) return hipErrorInvalidValue;
+            auto kern = bf16_filter_kernel<KS, M, false, CI, 2, false, true>;
+            static LdsAttrOnce lds_attr;
+            const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
+            if (e != hipSuccess) return e;
+            const BfShared a{shp->pcnt, shp->done, (uint32_t)n_wg, shp->epoch, shp->rank, (uint32_t)cb.nseg};
+            hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg + shp->n_refresh)), dim3(256), sh, s,
+                               static_cast<const char *>(img), n_tiles, static_cast<const u32x4 *>(B), q_tiles, kp,
+                               static_cast<uint2 *>(cb.keys), cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad, split,
+                               spp, scout_max, tau_init, scout_out, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
     if (scout_out) {
         if (RAD) return hipErrorInvalidValue;
@@ -2040,21 +2260,23 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
 template <int KS, bool CI>
 static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
-                                const uint32_t *tau_init, bool radius, float *scout_out, hipStream_t s) {
+                                const uint32_t *tau_init, bool radius, float *scout_out, const Bf16Shared *shp,
+                                hipStream_t s) {
     if (radius)
-        return cb.cap == 256 && tau_init ? launch_bf16_t<KS, 4, true, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split,
-                                                                          spp, scout_max, tau_init, nullptr, s)
-                                         : hipErrorInvalidValue;
+        return cb.cap == 256 && tau_init && !shp ? launch_bf16_t<KS, 4, true, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg,
+                                                                                  split, spp, scout_max, tau_init,
+                                                                                  nullptr, nullptr, s)
+                                                 : hipErrorInvalidValue;
     switch (cb.cap) {
         case 64:
             return launch_bf16_t<KS, 1, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
-                                                   tau_init, scout_out, s);
+                                                   tau_init, scout_out, shp, s);
         case 128:
             return launch_bf16_t<KS, 2, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
-                                                   tau_init, scout_out, s);
+                                                   tau_init, scout_out, shp, s);
         case 256:
             return launch_bf16_t<KS, 4, false, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg, split, spp, scout_max,
-                                                   tau_init, scout_out, s);
+                                                   tau_init, scout_out, shp, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -2066,15 +2288,25 @@ int bf16_segments(size_t q_tiles, int n_wg, int split) {
     return split * mfma_v2_max_segments(q_tiles * (size_t)split, n_wg);
 }
 
+bool bf16_shared_supported(int cap) {
+#ifdef PN_DIAG_BF_CAPT
+    return false;
+#else
+    return cap == 64 || cap == 128;
+#endif
+}
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
-                              bool ci, hipStream_t s) {
+                              bool ci, hipStream_t s, const Bf16Shared *shp) {
     if (!bf16_supported(dim) || bf16_is_wide(dim) || cb.nq_pad % kBQ || kp < 1 || kp + 32 > cb.cap || cb.idx_stride != 2 ||
         cb.idx != static_cast<uint32_t *>(cb.keys) + 1 || split < 1 || scout_max < 0 || (ci && !bf16_ci_dim(dim)))
         return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n + kBP - 1) / kBP);
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kBQ);
     if ((uint32_t)split > n_tiles) return hipErrorInvalidValue;
+    if (shp && (!(split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0) || !bf16_shared_supported(cb.cap) ||
+                shp->epoch < 1 || shp->epoch > 4095 || shp->rank < 1 || !shp->pcnt || !shp->done))
+        return hipErrorInvalidValue;  // shared thresholds need the aligned partition (exactly nseg cells per query)
     const uint32_t spp = (uint32_t)mfma_v2_max_segments((size_t)q_tiles * split, n_wg);
     // a whole number of workgroups per query tile (and no row parts): every (segment, query) cell has exactly one
     // writer and there are exactly n_wg / q_tiles segments
@@ -2082,7 +2314,16 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     if (cb.nseg < (aligned ? n_wg / (int)q_tiles : (int)(spp * split))) return hipErrorInvalidValue;
     const uint32_t sp = (uint32_t)split, sm = (uint32_t)scout_max;
 #define PN_BF_CASE(K, C) \
-    case K: return launch_bf16_m<K, C>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, s);
+    case K: return launch_bf16_m<K, C>(img, n_tiles, B, q_tiles, (uint32_t)kp, cb, n_wg, sp, spp, sm, tau_init, radius, scout_out, shp, s);
+#ifdef PN_DEV_KS8_ONLY  // development builds: only the D = 128 CI instantiation (compiles in a fraction of the time)
+    if (ci) {
+        switch (bf16_ks_for(dim, true)) {
+            PN_BF_CASE(8, true)
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipErrorInvalidValue;
+#else
     if (ci) {
         switch (bf16_ks_for(dim, true)) {
             PN_BF_CASE(2, true) PN_BF_CASE(3, true) PN_BF_CASE(4, true) PN_BF_CASE(5, true) PN_BF_CASE(6, true)
@@ -2095,6 +2336,7 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
         PN_BF_CASE(7, false) PN_BF_CASE(8, false) PN_BF_CASE(9, false)
         default: return hipErrorInvalidValue;
     }
+#endif
 #undef PN_BF_CASE
 }
 

@@ -136,13 +136,16 @@ struct Workspace {
     DevBuf w_bq, w_qn, w_qbad, w_gq, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
     DevBuf w_hq, w_hidx, w_hdist;  // staging of the host entry points (queries up, results down)
     DevBuf w_fparts;               // second tier, many-segment path: per-group partial results
+    DevBuf w_pcnt;                 // shared thresholds: the segments' published fill counts [nseg][nq_pad]
+    uint32_t sh_epoch = 0;         // epoch of the last launch that published into w_pcnt (1 .. 4095)
+    size_t sh_nseg = 0, sh_nq_pad = 0;  // geometry w_pcnt was last used with (a change: zero it once)
     hipStream_t stream = nullptr;  // the host entry points run here
     hipEvent_t done = nullptr;
     hipStream_t last_stream = nullptr;
     bool in_flight = false;
-    DevBuf *all[28] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
+    DevBuf *all[29] = {&w_q, &w_qnorm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
                        &w2_cnt, &w2_tau, &w_lo, &w_bq, &w_qn, &w_qbad, &w_gq, &w_gidx, &w_gdist, &w_gsel, &w_seed,
-                       &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist, &w_fparts};
+                       &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist, &w_fparts, &w_pcnt};
     std::vector<void *> retired;  // outgrown allocations, freed once `done` has passed (DevBuf::ensure)
     Workspace() {
         for (DevBuf *b : all) b->retired = &retired;
@@ -192,6 +195,7 @@ struct pn_index {
     int profile = 0;
     int filter_slots = 0;
     int mfma_structure = 0;  // 0 auto, 1 = grid of (query tile x segment), 2 = persistent balanced partition
+    int shared_tau = 1;      // PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto, >= 2 the rank itself
     // state that queries on a shared `const pn_index *` update: internally synchronised by `mu`
     struct Shared {
         std::mutex mu;
@@ -704,6 +708,10 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             if (value < 0 || value > 3) return fail(PN_ERR_INVALID, "bad structure");
             ix->mfma_structure = (int)value;
             return PN_OK;
+        case PN_OPT_SHARED_THRESHOLDS:
+            if (value < 0 || value > 4096) return fail(PN_ERR_INVALID, "bad shared-threshold rank");
+            ix->shared_tau = (int)value;
+            return PN_OK;
         default: return fail(PN_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -951,6 +959,8 @@ struct Bf16Plan {
     // wide rows (D > 128): per_tile workgroups per query tile, each a row range; 2 * per_tile segments per query
     bool wide;
     int per_tile;
+    // shared thresholds (bf16_filter.hip): refresher workgroups behind the n_wg main ones, rank of the shared threshold
+    int n_refresh, sh_rank;
 };
 // Wide rows: one workgroup per CU at a time (128 KiB of LDS), a whole number of workgroups per query tile: every cell
 // then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
@@ -1144,6 +1154,24 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         }
     }
 #endif
+    // Shared thresholds: with the whole grid resident (main workgroups + refreshers <= the 2 n_cu workgroup slots) the
+    // slots the aligned partition leaves idle run refreshers.  r = R + 5.5 sqrt(R) (k = 10: 51): on uniform 1M x 128
+    // data the rows whose bound lies below the 10th neighbour's distance number 22 +- 5.3 (max 44 over 256 queries,
+    // heavier-tailed than Poisson); a query with r or more of them only goes to the next tier.  Measured over 10^6
+    // queries (tools/sh_fallback_rate.py): unproven queries 4 without shared thresholds (a segment's k' overflows),
+    // 4 at r = 56 .. 80, 5 at r = 48; r = 40: 5 10^-5, r = 32: 3 10^-3.
+    p.n_refresh = 0;
+    p.sh_rank = 0;
+    if (p.shared_scout && p.aligned && ix->shared_tau != 0 && bf16_shared_supported(p.cap)) {
+        const int slots = 2 * ix->n_cu - p.n_wg;
+        const int rank = ix->shared_tau >= 2 ? ix->shared_tau : (int)std::ceil(R + 5.5 * std::sqrt(R));
+        // (a refresher holds up to 512 keys of a query's union in registers; a refresher pass over the queries takes
+        // ~0.25 ms, so short runs end before it pays: a 125 k-row shard of C2, 163 tiles per run, measured 2 % slower)
+        if (slots >= 4 && rank <= 256 && rank < p.nseg * p.cap && r_tiles / per_tile >= 512) {
+            p.n_refresh = slots > 64 ? 64 : slots;
+            p.sh_rank = rank;
+        }
+    }
     return p;
 }
 // f32 MFMA filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for flagged queries
@@ -1266,7 +1294,22 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
         if (plan.wide)
             HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg, 0,
                                            (const uint32_t *)ws.w_seed.p, false, nullptr, s));
-        else
+        else if (plan.n_refresh > 0) {
+            // shared thresholds: published counts tagged with this launch's epoch; d_misc[8] (zeroed with d_misc at the
+            // start of the call) counts the main workgroups that are done
+            const void *pc_before = ws.w_pcnt.p;
+            PNCHK(ws.w_pcnt.ensure(cells * sizeof(uint32_t)));
+            if (ws.w_pcnt.p != pc_before) ws.sh_nseg = 0;  // a fresh allocation holds anything
+            if (ws.sh_nseg != (size_t)nseg || ws.sh_nq_pad != nq_pad) {  // other geometry: stale words could carry any epoch
+                HIPCHK(hipMemsetAsync(ws.w_pcnt.p, 0, cells * sizeof(uint32_t), s));
+                ws.sh_nseg = (size_t)nseg;
+                ws.sh_nq_pad = nq_pad;
+            }
+            ws.sh_epoch = ws.sh_epoch % 4095u + 1u;
+            const Bf16Shared shp{(uint32_t *)ws.w_pcnt.p, d_misc + 8, ws.sh_epoch, (uint32_t)plan.sh_rank, plan.n_refresh};
+            HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, 0,
+                                      (const uint32_t *)ws.w_seed.p, false, nullptr, ix->bf16_ci, s, &shp));
+        } else
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, 0,
                                       (const uint32_t *)ws.w_seed.p, false, nullptr, ix->bf16_ci, s));
     } else if (plan.wide) {

@@ -212,9 +212,19 @@ int bf16_segments(size_t q_tiles, int n_wg, int split);
 // fixed thresholds (tau_init required, cb.cap == 256), buffers overflow (count = cap + 1) instead of compacting
 // scout_out (nullable): scout-only launch -- no buffers are touched; every run leaves its lanes' smallest block
 // minima in scout_out[cell][2][bf16_scout_list()] (pre-filled with +inf by the caller)
+// shp (nullable; main pass of an aligned k-NN plan with tau_init only): shared thresholds -- n_refresh extra "refresher"
+// workgroups merge what the segments of a query hold and lower the query's word in tau_init while the pass runs
+// (bf16_filter.hip, "Shared thresholds").  pcnt: [nseg][nq_pad] words (zeroed whenever the geometry changes), done: one
+// word, ZEROED before the launch; epoch 1 .. 4095, different from the previous launch on pcnt; rank: r-th smallest.
+struct Bf16Shared {
+    uint32_t *pcnt, *done;
+    uint32_t epoch, rank;
+    int n_refresh;
+};
+bool bf16_shared_supported(int cap);
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
-                              bool ci, hipStream_t s);
+                              bool ci, hipStream_t s, const Bf16Shared *shp = nullptr);
 // wide rows: n_wg persistent workgroups (one per CU) over equal slices of the (query tile, row tile) list;
 // cb.nseg >= bf16_wide_segments(q_tiles, n_wg) (a workgroup's two row halves are two segments); cells without a writer
 // must read "empty" unless n_wg is a multiple of q_tiles; scout_max in 256-row tiles

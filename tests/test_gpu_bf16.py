@@ -322,3 +322,29 @@ def test_narrow_partition_edge_cases(pn, oracle_mod):
     sel = np.random.default_rng(37).choice(nq, 300, replace=False)
     oidx, odist = oracle_mod.brute_knn(pts, qs[sel], k)
     assert dist[sel].tobytes() == odist.tobytes() and np.array_equal(idx[sel], oidx)
+
+
+def test_shared_thresholds_only_change_the_candidate_count(pn, oracle_mod):
+    """Shared thresholds (bf16_filter.hip): refresher workgroups lower every segment's threshold to the r-th smallest bound
+    of the union of what the segments of a query hold, while the filter runs.  Any such threshold is valid -- the
+    answers must be bit-identical with the option off, on, and with a rank so small (r = 2) that the thresholds drop
+    below the true neighbours and nearly every query has to be answered by the next tier."""
+    from petal_neighbors_amd import _lib
+    n, dim, nq, k = 300_000, 128, 3000, 10  # 12 query tiles x 32 segments = 384 main workgroups, refreshers behind them
+    pts, qs = uniform((n, dim), 3101), uniform((nq, dim), 3102)
+    want_i, want_d = oracle_mod.brute_knn(pts, qs[:200], k)
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine("bf16")
+    got = {}
+    for mode in (0, 1, 24, 2):  # (r = 2 last: its unproven queries make the index plan conservatively from then on)
+        tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, mode)
+        tree.stats(reset=True)
+        for _ in range(3):  # consecutive calls on one workspace: the epoch of the published words changes every call
+            idx, dist = tree.query_batch(qs, k)
+        st = tree.stats()
+        got[mode] = (idx, dist, st["candidates"] / st["queries"], st["fallback_queries"])
+        assert np.array_equal(idx[:200], want_i) and dist[:200].tobytes() == want_d.tobytes(), mode
+        assert np.array_equal(idx, got[0][0]) and dist.tobytes() == got[0][1].tobytes(), mode
+    assert got[0][3] <= 3 and got[1][3] <= 3          # benign data: (nearly) everything proven, with or without
+    assert got[1][2] < got[0][2]                      # the default rank keeps fewer candidates than no sharing
+    assert got[2][3] > nq // 2                        # r = 2: most queries of its first call went to the next tier

@@ -14,8 +14,9 @@ torch.cuda.synchronize()
 t = pn.BallTree.from_device(pts)
 t.set_engine("bf16")
 if slots: t.set_option(_lib.PN_OPT_FILTER_SLOTS, slots)
+if os.environ.get('PN_SH') is not None: t.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, int(os.environ['PN_SH']))
 f = L.pn_debug_read_bf; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int]
-out = (C.c_ulonglong * 12)()
+out = (C.c_ulonglong * 16)()
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 t.query_device(qs, k); torch.cuda.synchronize(); f(out, 1)
 waves = 480 * 4
@@ -33,3 +34,8 @@ print("  tile top to chain 1 (fragment + norm reads issued, LDS-DMA issue, check
 print("  chain 1 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(9) / waves, 100.0 * cyc(9) / waves / run, cyc(9) / waves / 1302))
 print("  chain 2 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(10) / waves, 100.0 * cyc(10) / waves / run, cyc(10) / waves / 1302))
 print("  in-kernel clock (s_memtime / s_memrealtime x 100 MHz) %.3f GHz; run = %.3f ms" % (cyc(7) / max(cyc(11), 1) * 0.1, cyc(11) / waves * 1e-5))
+
+if out[12]:
+    print("  refreshers: %d query visits, %d updates, %d passes over all refresher waves (%.1f per wave), %d rejected (a word changed)" %
+          (out[12], out[13], out[14], out[14] / 128.0, out[15]))
+print("  fallback queries %d, candidates per query %.1f" % (t.stats()["fallback_queries"], t.stats()["candidates"] / max(t.stats()["queries"], 1)))
