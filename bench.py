@@ -181,6 +181,50 @@ def verify(out, queries, n, dim, nq, k, rank, world, index, gen):
     return res
 
 
+def verify_radius(out, q_host, n, dim, nq, radius, tree):
+    """Parity leg of --mode radius, outside the timed region: every list ascending, in range and free of duplicates;
+    the lists of sampled queries against the exact engine (the two-pass CSR scan under Euclidean::distance) and, for
+    corpora of at most 2M rows, against the oracle's brute force over a host-generated corpus; every returned
+    (query, row) pair of the sample re-derived with the scalar metric: distance < radius."""
+    import oracle
+    import petal_neighbors_amd as pn
+    off, ids = out
+    res = {"ok": True, "checks": []}
+
+    def chk(name, ok):
+        res["checks"].append(name if ok else name + ": FAILED")
+        res["ok"] = res["ok"] and bool(ok)
+
+    chk("offsets monotone, total = len(ids)", bool((np.diff(off.astype(np.int64)) >= 0).all()) and int(off[-1]) == len(ids))
+    chk("in range", bool((ids < n).all()) if len(ids) else True)
+    asc = True
+    for a in np.linspace(0, nq - 1, min(nq, 4096)).astype(np.int64):
+        l = ids[int(off[a]):int(off[a + 1])].astype(np.int64)
+        asc = asc and bool((np.diff(l) > 0).all())
+    chk("lists strictly ascending (sampled)", asc)
+    sel = np.linspace(0, nq - 1, 48).astype(np.int64)
+    tree.set_engine("exact")
+    eo, ei = tree.query_radius_batch(q_host[sel], radius)
+    tree.set_engine("auto")
+    chk("exact engine on 48 queries", all(np.array_equal(ids[int(off[a]):int(off[a + 1])], ei[int(eo[j]):int(eo[j + 1])])
+                                        for j, a in enumerate(sel)))
+    m = pn.distance.Euclidean()
+    ok, pairs = True, 0
+    for a in sel:
+        for row in ids[int(off[a]):int(off[a + 1])][:4]:
+            p = oracle.fill_uniform(dim, SEED_P, int(row) * dim)
+            ok = ok and bool(m.distance(q_host[a], p) < np.float32(radius))
+            pairs += 1
+    chk(f"Euclidean::distance(query, points[idx]) < r on {pairs} returned pairs", ok)
+    if n <= 2_000_000:
+        pts = oracle.fill_uniform(n * dim, SEED_P).reshape(n, dim)
+        osel = sel[:16]
+        chk("oracle brute force on 16 sampled queries",
+            all(np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle.brute_radius(pts, q_host[a], np.float32(radius)))
+                for a in osel))
+    return res
+
+
 def plumbing(args):
     """--config c1: the reference's own harness shapes and call pattern (benches/ball_tree.rs:8-62) -- f64, one point
     per call through the host API, queries = corpus rows -- plus BASELINE.json's configs[0] shape (1000 x 3, k = 2) and
@@ -256,6 +300,11 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
     ap.add_argument("--structure", type=int, default=0, help="PN_OPT_MFMA_STRUCTURE; 0 = auto")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity leg (outside the timed region)")
+    ap.add_argument("--mode", default="knn", choices=["knn", "radius"],
+                    help="radius: BallTree::query_radius over the batch (host queries in, host CSR out), one GPU")
+    ap.add_argument("--radius", default="0.5",
+                    help="radius of --mode radius (BASELINE configs[2]: 0.5); 'nn' = the median nearest-neighbour distance "
+                         "of the queries x 1.0005, so that about half of the lists are non-empty")
     ap.add_argument("--shared-thresholds", type=int, default=-1,
                     help="PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto (library default), >= 2 the rank itself")
     ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
@@ -345,6 +394,8 @@ def main():
             tree.set_option(_lib.PN_OPT_FILTER_SLOTS, args.slots)
         if args.structure:
             tree.set_option(_lib.PN_OPT_MFMA_STRUCTURE, args.structure)
+        if os.environ.get("PN_BENCH_EXCHANGE") == "1" and args.comm == "abi":
+            tree.set_option(_lib.PN_OPT_EXCHANGE_ALWAYS, 1)  # rehearsal of the N > 1 path on one GPU (tests)
         if args.shared_thresholds >= 0:
             tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, args.shared_thresholds)
         tree.set_option(_lib.PN_OPT_PROFILE, 1)
@@ -353,7 +404,21 @@ def main():
     out_dst = torch.empty((nq, min(k, n)), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
+    radius = None
+    if args.mode == "radius":
+        if world != 1 or tree is None:
+            sys.exit("bench.py: --mode radius runs on one GPU")
+        q_host = queries.cpu().numpy()
+        if args.radius == "nn":
+            _, d1 = tree.query_device(queries[:2048].contiguous(), 1)
+            torch.cuda.synchronize()
+            radius = float(np.float32(float(torch.median(d1[:, 0]).item()) * 1.0005))
+        else:
+            radius = float(np.float32(float(args.radius)))
+
     def step():
+        if args.mode == "radius":  # the reference's call, batched: host queries in, host CSR out (sizes are data-dependent)
+            return tree.query_radius_batch(q_host, radius)
         if args.comm == "abi":  # results land in preallocated buffers: nothing but the one C call per step
             return index.engine.index.query_device(queries, k, out_idx, out_dst)
         return index.query_batch(queries, k)
@@ -382,7 +447,9 @@ def main():
                                                  "queries": 0, "evaluations": 0}
 
     verified = None
-    if not args.no_verify:
+    if not args.no_verify and args.mode == "radius":
+        verified = verify_radius(out, q_host, n, dim, nq, radius, tree)
+    elif not args.no_verify:
         verified = verify(out, queries, n, dim, nq, k, rank, world, index, gen)
         if dist:
             v = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
@@ -418,17 +485,24 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
                 pmc = json.load(open(f))
-                if pmc.get("kernel") == kernel_name and pmc.get("config") == args.config and world == 1:
+                if pmc.get("kernel") == kernel_name and world == 1 and \
+                        pmc.get("config") == args.config + ("_radius" if args.mode == "radius" else ""):
                     traffic, traffic_src = pmc["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             pass
+        if args.mode == "radius":
+            kernel_name = "bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel"
         line = {
-            "metric": "exact k-NN queries/sec (1M x 128 fp32, k=10)" if args.config == "c2"
-                      else f"exact k-NN queries/sec ({n} x {dim} fp32, k={k})",
+            "metric": (f"exact radius queries/sec ({n} x {dim} fp32, r={radius:.6g})" if args.mode == "radius" else
+                       "exact k-NN queries/sec (1M x 128 fp32, k=10)" if args.config == "c2"
+                       else f"exact k-NN queries/sec ({n} x {dim} fp32, k={k})"),
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n} points x {dim} dims f32, {nq} queries, k={k}, uniform[0,1)",
+            "config": {"workload": (f"{args.config} radius: {n} points x {dim} dims f32, {nq} queries, query_radius r={radius:.6g}, "
+                                    f"uniform[0,1); host queries in, host CSR out (the API's boundary: list sizes are "
+                                    f"data-dependent), so value includes the transfers" if args.mode == "radius" else
+                                    f"{args.config}: {n} points x {dim} dims f32, {nq} queries, k={k}, uniform[0,1)"),
                        "n_points": n, "dim": dim, "n_queries": nq, "k": k, "engine": engine_used,
                        "sharding": f"corpus rows / {world}" if world > 1 else "none",
                        "exchange": ("none (one shard)" if world == 1 else
@@ -447,6 +521,11 @@ def main():
                                                   / (peak * world), 4)},
             "verified": bool(verified["ok"]) if verified else None,
             "verify": verified,
+            **({"radius": radius, "results_per_query": round(float(out[0][-1]) / nq, 4)} if args.mode == "radius" else {}),
+            # N > 1 (or a forced exchange): the step's local half (this rank's filter + re-rank over its shard) and its
+            # exchange half (ncclAllGather + merge), hipEvents on the call's stream inside the library, rank 0's
+            **({"shard_ms": round(st["shard_ms"] / max(args.steps, 1), 4),
+                "exchange_ms": round(st["exchange_ms"] / max(args.steps, 1), 4)} if st.get("exchange_ms", 0.0) > 0.0 else {}),
             "fallback_queries": int(st["fallback_queries"]),
             "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
             "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),

@@ -81,7 +81,8 @@ enum {
     PN_OPT_ENGINE = 1,
     PN_OPT_SEGMENTS = 2,    /* corpus row segments per query tile; 0 = auto */
     PN_OPT_INDEX_BASE = 3,  /* added to every returned index (row-sharded corpora) */
-    PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream */
+    PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream (hot_ms); 2: also the whole
+                               call (last_call_ms) -- every event record costs the stream a few microseconds */
     PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
     PN_OPT_MFMA_STRUCTURE = 6, /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
                                  buffers, 1 workgroup/CU; 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU */
@@ -120,7 +121,10 @@ typedef struct pn_stats {
     uint64_t radius_results;
     uint64_t evaluations;      /* candidates whose exact distance was actually computed (the others were proven
                                   farther than the k-th from their filter bound alone) */
-    uint64_t reserved[3];
+    double shard_ms;           /* pn_sharded_* under PN_OPT_PROFILE: summed hipEvent time of the local half of the calls
+                                  (every local shard's filter + re-rank + local merge) ... */
+    double exchange_ms;        /* ... and of their exchange half (pack is in the local half; ncclAllGather + final merge) */
+    uint64_t reserved[1];
 } pn_stats;
 
 const char *pn_last_error(void);

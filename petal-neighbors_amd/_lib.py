@@ -32,7 +32,7 @@ class PnStats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("fallback_queries", C.c_uint64), ("candidates", C.c_uint64),
                 ("hot_launches", C.c_uint64), ("hot_ms", C.c_double), ("last_call_ms", C.c_double),
                 ("radius_results", C.c_uint64), ("evaluations", C.c_uint64),
-                ("reserved", C.c_uint64 * 3)]
+                ("shard_ms", C.c_double), ("exchange_ms", C.c_double), ("reserved", C.c_uint64 * 1)]
 
 
 class PnShardedInfo(C.Structure):

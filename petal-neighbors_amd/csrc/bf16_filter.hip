@@ -356,13 +356,18 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
 // them): coalesced 16-byte loads and stores instead of one thread walking 128 coordinates and storing them two bytes at
 // a time (C2: 37 -> ~8 us per batch).  The three f64 sums are reduced over the eight lanes; their rounding differs
 // from the sequential sums' by ~1e-16 relative, which the factors kUp (1 + 2^-40) cover as before.
+// Qp (nullable): the call's FIRST kernel -- Q then is the caller's query array itself (row stride ld, at least dim
+// columns), and this kernel also writes the zero-padded f32 copy Qp[nq_pad][ldq] that the re-rank and the next tier read
+// (pack_rows_kernel's job) and zeroes the call's 16 counter words `misc` (a memset's job): one launch instead of three.
 __global__ void bf16_pack_queries8_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
                                           size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
                                           double *__restrict__ qn, uint32_t *__restrict__ qbad, int ci, double bmax,
-                                          double dmax) {
+                                          double dmax, float *__restrict__ Qp, size_t ldq,
+                                          uint32_t *__restrict__ misc) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t q = t >> 3;
     const int sub = (int)(t & 7);
+    if (misc && t < 16) misc[t] = 0u;
     if (q >= nq_pad) return;  // (whole groups of eight leave together: nq_pad * 8 is a multiple of the block size)
     const int K = 16 * KS, CH = 2 * KS, E = bf16_extra_col(dim);
     const int c0 = sub * CH;
@@ -370,12 +375,44 @@ __global__ void bf16_pack_queries8_kernel(const float *__restrict__ Q, const flo
     double s = 0.0, en = 0.0, hn = 0.0;
     bool finite = true;
     const float *src = Q + q * ld;
+    if (Qp) {  // columns of the padded copy that no lane's eighth of the K columns covers (ldq > K, e.g. D = 100)
+        for (int k = K + sub; k < (int)ldq; k += 8) Qp[q * ldq + k] = 0.0f;
+    }
+    // this lane's CH coordinates: 16-byte loads when the source rows allow it (the usual case: a contiguous array
+    // with a multiple of four columns), and 16- or 8-byte stores into the padded copy (its rows are 32-byte aligned)
+    float xf[18];
+    const bool in_rows = q < nq;
+    const bool vec = (CH % 4) == 0 && ((reinterpret_cast<uintptr_t>(Q) | (ld * sizeof(float))) & 15u) == 0 &&
+                     c0 + CH <= dim;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) xf[i] = 0.0f;
+    if (in_rows) {
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < 18; i += 4)
+                if (i + 4 <= CH) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(src + c0 + i);
+                    xf[i] = t4.x; xf[i + 1] = t4.y; xf[i + 2] = t4.z; xf[i + 3] = t4.w;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i)
+                if (i < CH && c0 + i < dim) xf[i] = src[c0 + i];
+        }
+    }
+    if (Qp) {
+        float *qd = Qp + q * ldq + c0;
+#pragma unroll
+        for (int i = 0; i < 18; i += 2)
+            if (i + 2 <= CH && c0 + i + 2 <= (int)ldq)  // (CH and ldq are even: pairs never straddle the row end)
+                *reinterpret_cast<float2 *>(qd + i) = make_float2(xf[i], xf[i + 1]);
+    }
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         v[i] = 0;
         const int k = c0 + i;
         if (i < CH && k < dim && q < nq) {
-            const float x = src[k];
+            const float x = xf[i];
             finite = finite && (fabsf(x) < 1.0e30f);
             const double c = (double)x - (double)mu[k];
             const float cf = (float)c;
@@ -1177,7 +1214,21 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     constexpr bool TAG = M >= kBfTagFromM;
     constexpr int TB = kBP * CP * 16;  // bytes per tile image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    char *tiles = reinterpret_cast<char *>(smem_raw);  // [3][TB]
+    char *tiles = reinterpret_cast<char *>(smem_raw);  // [NBUF][TB] (the scout pass uses two of them)
+    // the workgroup's arrival counter of the split tile barrier (main loop), behind the three tile buffers
+    constexpr int NBUF = 3;
+    // Split tile barrier (below) for the kernels whose survivors are frequent (buffers of 128 slots and more: k' > 16).
+    // Measured on one device, full s_barrier vs split: 1M x 128 k = 100 3.62 -> 3.46 ms per step; C2 (64-slot buffers,
+    // shared thresholds) 2.29 vs 2.31-2.36: not there.  A fourth tile buffer (landing waited for 1.5 tiles after the
+    // request instead of 0.5) made C2 4 % slower and changed nothing at k = 100: the wait is not LDS-DMA latency.
+#ifdef PN_DIAG_BF_FULLBARRIER
+    constexpr bool kSplit = false;
+#elif defined(PN_DIAG_BF_SPLITBARRIER)
+    constexpr bool kSplit = true;
+#else
+    constexpr bool kSplit = M >= 2;
+#endif
+    volatile uint32_t *arrive = reinterpret_cast<volatile uint32_t *>(tiles + NBUF * TB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1217,15 +1268,16 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
     unsigned long long u0 = w * U / W;
     const unsigned long long u1 = (w + 1) * U / W;
 
+    // wave w moves the consecutive pieces [w P, w P + P) of a tile
+    constexpr int P = (CP + 3) / 4;
+    const int n_mine = CP - wave * P < P ? (CP - wave * P > 0 ? CP - wave * P : 0) : P;  // (the last wave may have fewer)
     auto dma_tile = [&](uint32_t rt, int buf) {
         const char *src = img + (size_t)rt * (size_t)TB + lane * 16;
         char *dst = tiles + buf * TB;
-        // wave w moves the consecutive pieces [w P, w P + P): one address register and one M0 value serve four pieces
-        // through the instruction's immediate offset (which advances the global and the LDS address alike)
-        constexpr int P = (CP + 3) / 4;
+        // one address register and one M0 value serve four pieces through the instruction's immediate offset (which
+        // advances the global and the LDS address alike)
         const char *ws = src + wave * (P * 1024);
         char *wd = dst + wave * (P * 1024);
-        const int n_mine = CP - wave * P < P ? CP - wave * P : P;  // pieces of this wave (the last wave may have fewer)
 #ifndef PN_DIAG_BF_NODMA  // NODMA is timing-only: tiles are never loaded
         static_assert(P <= 5, "piece schedule written out for up to five pieces per wave");
         if (0 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 0, 0);
@@ -1416,7 +1468,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         __syncthreads();  // previous run's readers are done with the buffers
         dma_tile(rt0, 0);
         if (rt0 + 1 < rt1) dma_tile(rt0 + 1, 1);
-        __syncthreads();  // carries the vmcnt(0): tiles rt0 and rt0 + 1 are in LDS
+        if (tid == 0) *arrive = 0u;
+        __syncthreads();  // carries the vmcnt(0): the first NBUF - 1 tiles are in LDS
         f32x16 a00, a01, a10, a11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // "nothing here yet": above every threshold
@@ -1441,12 +1494,26 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         uint32_t g0 = 0, g1 = 0, sh_ncomp = 0;  // sh_ncomp: this wave's compactions so far (wave-uniform)
         bool g_pending = false;  // (wave-uniform)
         for (uint32_t rt = rt0; rt < rt1; ++rt) {
-            const int nxt = cur == 2 ? 0 : cur + 1, prv = cur == 0 ? 2 : cur - 1;
+            const int nxt = cur == NBUF - 1 ? 0 : cur + 1, prv = cur == 0 ? NBUF - 1 : cur - 1;
             const bool sh_point = SH && ((rt - rt0) % kShPeriod) == kShPeriod - 1;  // (wave-uniform)
             const char *tb = tiles + cur * TB;
             const char *arow0 = tb + (jq * CP + h) * 16;
             const char *arow1 = arow0 + 32 * CP * 16;
             float m0, m1, p0, p1;
+            // SPLIT TILE BARRIER (kSplit).  What the workgroup's one meeting per tile certifies -- every wave's LDS-DMA pieces of
+            // tile rt+1 have landed, and nobody reads tile rt-1 any more (its buffer takes tile rt+2) -- is true of THIS
+            // wave here, at the top of tile rt, and is needed only in the middle of the tile, a whole MFMA chain and a
+            // survivor check later.  So the wave ARRIVES here (its pieces have landed: the counted vmcnt wait; its reads
+            // of tile rt-1 are older LDS operations than the add, and LDS operations of a wave execute in order) and
+            // WAITS in the middle, for a count instead of at an s_barrier: a sibling delayed by up to a chain -- the one
+            // rare-path entry that made the other three wait at every such barrier (a wave's time at the barrier was
+            // 26 % of its run, most of it waiting for siblings' detours) -- no longer stops anybody.
+            if (kSplit && rt > rt0) {
+#if !defined(PN_DIAG_BF_NOWAIT)
+                bf_wait_dma(ns);
+#endif
+                if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(arrive), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
 #if defined(PN_DIAG_BF_COUNT)
             unsigned long long tc0_ = bf_stamp_nw();
 #endif
@@ -1469,15 +1536,27 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
 #if defined(PN_DIAG_BF_COUNT)
             const unsigned long long tb0_ = bf_stamp();
 #endif
+            if (!kSplit) {  // everything at one s_barrier in the middle of the tile
 #if !defined(PN_DIAG_BF_NOWAIT)  // NOWAIT is timing-only: tiles may be read before they landed
-            if (sh_point) ns = 0;  // a publish point: every entry stored so far must have reached memory (vmcnt(0))
-            bf_wait_dma(ns);
+                if (sh_point) ns = 0;  // a publish point: every entry stored so far must have reached memory (vmcnt(0))
+                bf_wait_dma(ns);
 #endif
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef PN_DIAG_BF_NOBARRIER  // NOBARRIER is timing-only
-            __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
 #endif
-            asm volatile("" ::: "memory");
+                asm volatile("" ::: "memory");
+            } else {
+                if (rt > rt0) {  // all four waves have arrived at tile rt (see the top of the loop)
+                    const uint32_t want = 4u * (rt - rt0);
+#ifndef PN_DIAG_BF_NOBARRIER
+                    while (*arrive < want) __builtin_amdgcn_s_sleep(1);
+#endif
+                }
+                asm volatile("" ::: "memory");
+                // a publish point: every entry stored so far must have reached memory before the counts that cover it
+                if (sh_point) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #if defined(PN_DIAG_BF_COUNT)
             BF_COUNT(6, bf_stamp() - tb0_);
 #endif
@@ -2146,6 +2225,14 @@ int bf16_cap_for(int kp) { return kp + 32 <= PN_DIAG_BF_CAP ? PN_DIAG_BF_CAP : 2
 int bf16_cap_for(int kp) { return kp <= 16 ? 64 : kp <= 64 ? 128 : 256; }
 #endif
 int bf16_query_tile() { return kBQ; }
+// entries a (segment, query) cell holds at most when a k-NN launch has finished: every run ends with a cut to k'
+int bf16_cell_max(int kp, int cap) {
+#ifdef PN_DIAG_BF_FINALCOMPACT_FROM
+    return cap;
+#else
+    return kp < cap ? kp : cap;
+#endif
+}
 
 // per-dimension sums of the corpus in f64 (any translation vector is valid; the mean minimises the norms);
 // sums[dim] receives the sum of all squares
@@ -2185,14 +2272,22 @@ hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, in
     return hipGetLastError();
 }
 
+bool bf16_pack_fused_supported(int dim) {
+#ifdef PN_DIAG_BF_PACKQ1
+    return false;
+#else
+    return !bf16_is_wide(dim);
+#endif
+}
 hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s) {
+                                    hipStream_t s, float *Qp, size_t ldq, uint32_t *misc) {
+    if ((Qp || misc) && !bf16_pack_fused_supported(dim)) return hipErrorInvalidValue;
 #ifndef PN_DIAG_BF_PACKQ1
     if (!bf16_is_wide(dim)) {  // nq_pad is a multiple of 256: whole blocks
         hipLaunchKernelGGL(bf16_pack_queries8_kernel, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
                            nq_pad, dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, ci ? 1 : 0,
-                           bmax, dmax);
+                           bmax, dmax, Qp, ldq, misc);
         return hipGetLastError();
     }
 #endif
@@ -2215,7 +2310,7 @@ template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, const Bf16Shared *shp, hipStream_t s) {
-    const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16;  // three tile buffers (software-pipelined main loop)
+    const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16 + 16;  // three tile buffers (software-pipelined main loop) + the arrival counter
 #define PN_BF_LAUNCH_MODE(MD)                                                                                          \
     {                                                                                                                   \
         auto kern = bf16_filter_kernel<KS, M, RAD, CI, MD, kBfCapture && (M > 1) && !RAD>;                                                             \

@@ -66,16 +66,21 @@ __device__ __forceinline__ double pn_sqrt(double x) { return sqrt(x); }
 // Pt/Qt point at row 0 of the tile; rows are zero padded to a multiple of 8
 // coordinates and row counts to a multiple of 64, so loads need no row guard.
 // ---------------------------------------------------------------------------
+// rowsel (nullable): the tile's rows are rows rowsel[0 .. n_valid) of src (a device-side selection list: the second
+// tier's flagged queries, read in place instead of gathered by a launch of their own); rows beyond n_valid read row
+// rowsel[0] -- they are masked by the caller.
 template <typename T>
 __device__ __forceinline__ void stage_chunk(const T *__restrict__ src, size_t ld, int kc0, int dim,
-                                            T (*dst)[kTileQ], int tid) {
+                                            T (*dst)[kTileQ], int tid, const uint32_t *__restrict__ rowsel = nullptr,
+                                            int n_valid = 0) {
     using V = typename Vec4<T>::type;
     const int row = tid & 63;
     const int kq = (tid >> 6) * 8;
     const int k0 = kc0 + kq;
     T v[8];
     if (k0 < dim) {  // dim <= ld, groups of 8 never straddle the padded row end
-        const T *p = src + (size_t)row * ld + k0;
+        const size_t srow = rowsel ? (size_t)rowsel[row < n_valid ? row : 0] : (size_t)row;
+        const T *p = src + srow * ld + k0;
         V a = *reinterpret_cast<const V *>(p);
         V b = *reinterpret_cast<const V *>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -96,7 +101,8 @@ __device__ __forceinline__ void stage_chunk(const T *__restrict__ src, size_t ld
 template <typename T, bool COS = false>
 __device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ldp, const T *__restrict__ Qt,
                                              size_t ldq, int dim, bool stage_q, T (&acc)[4][4],
-                                             T (*Qs)[kTileQ], T (*Ps)[kTileP], int tid, int qb, int pb) {
+                                             T (*Qs)[kTileQ], T (*Ps)[kTileP], int tid, int qb, int pb,
+                                             const uint32_t *__restrict__ qsel = nullptr, int q_valid = 0) {
 #pragma clang fp contract(off)
     using V = typename Vec4<T>::type;
 #pragma unroll
@@ -106,7 +112,7 @@ __device__ __forceinline__ void compute_tile(const T *__restrict__ Pt, size_t ld
 
     for (int kc0 = 0; kc0 < dim; kc0 += kChunkK) {
         __syncthreads();  // previous chunk fully consumed
-        if (stage_q || kc0 > 0 || dim > kChunkK) stage_chunk<T>(Qt, ldq, kc0, dim, Qs, tid);
+        if (stage_q || kc0 > 0 || dim > kChunkK) stage_chunk<T>(Qt, ldq, kc0, dim, Qs, tid, qsel, q_valid);
         stage_chunk<T>(Pt, ldp, kc0, dim, Ps, tid);
         __syncthreads();
         const int klen = (dim - kc0 < kChunkK) ? (dim - kc0) : kChunkK;
@@ -144,7 +150,8 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
     uint32_t kp, size_t seg_len, typename KeyOf<T>::type *__restrict__ ckey, uint32_t *__restrict__ cidx,
     uint32_t *__restrict__ ccnt, typename KeyOf<T>::type *__restrict__ ctau, size_t nq_pad,
     const typename KeyOf<T>::type *__restrict__ lo_key, const uint32_t *__restrict__ lo_idx,
-    const uint32_t *__restrict__ nq_dev, uint32_t nq_off, const T *__restrict__ pnorm, const T *__restrict__ qnorm) {
+    const uint32_t *__restrict__ nq_dev, uint32_t nq_off, const T *__restrict__ pnorm, const T *__restrict__ qnorm,
+    const uint32_t *__restrict__ qsel) {
     using KeyT = typename KeyOf<T>::type;
     constexpr uint32_t CAP = 64u * M;
     constexpr KeyT KMAX = KeyOf<T>::kMax;
@@ -173,7 +180,10 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
     if (tid < kTileQ) { taus[tid] = KMAX; cnts[tid] = 0; }
     __syncthreads();
 
-    const T *Qt = Q + q0 * ldq;
+    // qsel: query r of this launch is row qsel[nq_off + r] of Q (the flagged queries of a filter tier, in place)
+    const T *Qt = qsel ? Q : Q + q0 * ldq;
+    const uint32_t *qsel_t = qsel ? qsel + nq_off + q0 : nullptr;
+    const int q_valid = (int)((size_t)nq - q0 < (size_t)kTileQ ? (size_t)nq - q0 : (size_t)kTileQ);
     const size_t cbase0 = (seg * nq_pad + q0) * (size_t)CAP;
     // multi-round selection (k beyond one buffer): only entries strictly after (lo_key, lo_idx) in the
     // (key, row) order take part, i.e. the neighbours already returned by earlier rounds are skipped
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
     bool first = true;
     for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
         T acc[4][4];
-        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb, qsel_t, q_valid);
         first = false;
         T qn4[4] = {(T)0, (T)0, (T)0, (T)0}, pn4[4] = {(T)0, (T)0, (T)0, (T)0};
         if (COS) {
@@ -262,8 +272,9 @@ template <typename T>
 static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
                                    int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                    const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const T *pnorm,
-                                   const T *qnorm, hipStream_t s) {
+                                   const T *qnorm, hipStream_t s, const uint32_t *qsel = nullptr) {
     using KeyT = typename KeyOf<T>::type;
+    if (qsel && pnorm) return hipErrorInvalidValue;  // (the selection list serves the Euclidean second tier only)
     dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
     const bool cosm = pnorm != nullptr;
     auto *ck = static_cast<KeyT *>(cb.keys);
@@ -271,7 +282,7 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
 #define PN_LAUNCH1(MM, CC)                                                                               \
     hipLaunchKernelGGL((exact_knn_kernel<T, MM, CC>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq,      \
                        (uint32_t)kp, seg_len, ck, cb.idx, cb.cnt, ct, cb.nq_pad, static_cast<const KeyT *>(lo_key),  \
-                       lo_idx, nq_dev, nq_off, pnorm, qnorm)
+                       lo_idx, nq_dev, nq_off, pnorm, qnorm, qsel)
 #define PN_LAUNCH(MM)          \
     do {                       \
         if (cosm)              \
@@ -294,9 +305,9 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                 const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const float *pnorm,
-                                const float *qnorm, hipStream_t s) {
+                                const float *qnorm, hipStream_t s, const uint32_t *qsel) {
     return launch_exact_knn<float>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, pnorm,
-                                   qnorm, s);
+                                   qnorm, s, qsel);
 }
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,

@@ -140,6 +140,7 @@ struct Workspace {
     uint32_t sh_epoch = 0;         // epoch of the last launch that published into w_pcnt (1 .. 4095)
     size_t sh_nseg = 0, sh_nq_pad = 0;  // geometry w_pcnt was last used with (a change: zero it once)
     hipStream_t stream = nullptr;  // the host entry points run here
+    hipEvent_t ev_r[2] = {nullptr, nullptr};  // radius calls under PN_OPT_PROFILE: the filter launch's bracket
     hipEvent_t done = nullptr;
     hipStream_t last_stream = nullptr;
     bool in_flight = false;
@@ -166,7 +167,8 @@ struct CallRec {
     uint32_t *h_nflag = nullptr;  // pinned
     size_t nq = 0;
     uint64_t call_id = 0;
-    bool pending = false, busy = false, prof = false, two_launches = false, has_flag = false, bf16_tier = false, hot = false;
+    bool pending = false, busy = false, two_launches = false, has_flag = false, bf16_tier = false, hot = false;
+    int prof = 0;  // PN_OPT_PROFILE at rec_begin: 1 = the dominant kernel's brackets, 2 = also the whole chunk's
 };
 constexpr int kCallRecs = 16;
 
@@ -256,8 +258,8 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0)
             ix->n_cu = prop.multiProcessorCount;
     }
-    HIPCHK(hipMalloc((void **)&ix->d_stats, 4 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(ix->d_stats, 0, 4 * sizeof(unsigned long long), s));
+    HIPCHK(hipMalloc((void **)&ix->d_stats, kPnStatWords * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(ix->d_stats, 0, kPnStatWords * sizeof(unsigned long long), s));
     const size_t bytes = ix->n_pad * ix->ld * sizeof(T);
     HIPCHK(hipMalloc(&ix->d_pts, bytes ? bytes : 256));
     if (sizeof(T) == 4)
@@ -490,6 +492,8 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     for (Workspace *ws : ix->sh.all_ws) {
         for (DevBuf *b : ws->all) b->release();
         ws->free_retired();
+        for (hipEvent_t e : ws->ev_r)
+            if (e) (void)hipEventDestroy(e);
         if (ws->done) (void)hipEventDestroy(ws->done);
         if (ws->stream) (void)hipStreamDestroy(ws->stream);
         delete ws;
@@ -573,9 +577,15 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
     if (r.prof) {
         float ms = 0, a = 0, b = 0;
         if (r.hot) {
-            if (r.two_launches) {  // scout launch ev0..ev4, main launch ev5..ev1 (the seed kernel between them is not counted)
-                if (hipEventElapsedTime(&a, r.ev[0], r.ev[4]) == hipSuccess && hipEventElapsedTime(&b, r.ev[5], r.ev[1]) == hipSuccess) {
-                    sh.stats.hot_ms += a + b;
+            if (r.two_launches) {
+                // The dominant kernel ran twice (scout-only launch, main launch) inside ONE bracket ev0..ev1, with the
+                // one-wave-per-query seed kernel (~18 us at C2, < 1 %) between them: every event record costs the stream
+                // ~6 us, and separate brackets (round 2) were four of them per step.  hot_ms is therefore an upper
+                // bound of the two launches' time.
+                (void)a;
+                (void)b;
+                if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) {
+                    sh.stats.hot_ms += ms;
                     sh.stats.hot_launches += 2;
                 }
             } else if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) {
@@ -583,7 +593,7 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
                 sh.stats.hot_launches += 1;
             }
         }
-        if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) {
+        if (r.prof > 1 && hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) {
             if (sh.stats_call != r.call_id) {
                 sh.stats_call = r.call_id;
                 sh.stats.last_call_ms = 0.0;
@@ -635,7 +645,7 @@ static int rec_begin(const pn_index *ix, uint64_t call_id, size_t nq, CallRec **
         for (hipEvent_t &e : r.ev) HIPCHK(hipEventCreate(&e));
     r.nq = nq;
     r.call_id = call_id;
-    r.prof = ix->profile != 0;
+    r.prof = ix->profile;
     r.two_launches = r.has_flag = r.bf16_tier = r.hot = false;
     r.busy = true;
     *r.h_nflag = 0;
@@ -699,7 +709,7 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             ix->opt_segments = (int)value;
             return PN_OK;
         case PN_OPT_INDEX_BASE: ix->index_base = (uint64_t)value; return PN_OK;
-        case PN_OPT_PROFILE: ix->profile = value ? 1 : 0; return PN_OK;
+        case PN_OPT_PROFILE: ix->profile = value < 0 ? 0 : value > 2 ? 2 : (int)value; return PN_OK;
         case PN_OPT_FILTER_SLOTS:
             if (value < 0 || value > 960) return fail(PN_ERR_INVALID, "bad filter slot count");
             ix->filter_slots = (int)value;
@@ -725,12 +735,14 @@ extern "C" int pn_index_get_stats(const pn_index *ix, pn_stats *out, int reset) 
     HIPCHK(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(ix->sh.mu);
     recs_collect(ix, true);
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[kPnStatWords] = {0};  // [0] fallback queries, then kPnStatSlots pairs {candidates, evaluations}
     if (ix->d_stats) HIPCHK(hipMemcpy(h, ix->d_stats, sizeof h, hipMemcpyDeviceToHost));
     *out = ix->sh.stats;
     out->fallback_queries += h[0];
-    out->candidates += h[1];
-    out->evaluations += h[2];
+    for (int i = 0; i < kPnStatSlots; ++i) {
+        out->candidates += h[4 + 2 * i];
+        out->evaluations += h[5 + 2 * i];
+    }
     if (reset) {
         ix->sh.stats = pn_stats{};
         if (ix->d_stats) HIPCHK(hipMemset(ix->d_stats, 0, sizeof h));
@@ -785,15 +797,16 @@ template <> struct Ops<float> {
     }
     static hipError_t knn(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq, size_t ldq, int kp,
                           size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
-                          uint32_t no, const float *pn, const float *qn, hipStream_t s) {
-        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s);
+                          uint32_t no, const float *pn, const float *qn, hipStream_t s, const uint32_t *qsel = nullptr) {
+        return launch_exact_knn_f32(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s, qsel);
     }
     static hipError_t cnorms(const float *X, size_t n, int dim, size_t ld, float *o, hipStream_t s) {
         return launch_cosine_norms_f32(X, n, dim, ld, o, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, float *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s) {
-        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s);
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s,
+                             const uint32_t *osel = nullptr) {
+        return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s, osel);
     }
 };
 template <> struct Ops<double> {
@@ -802,14 +815,15 @@ template <> struct Ops<double> {
     }
     static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
                           size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
-                          uint32_t no, const double *pn, const double *qn, hipStream_t s) {
+                          uint32_t no, const double *pn, const double *qn, hipStream_t s, const uint32_t * = nullptr) {
         return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s);
     }
     static hipError_t cnorms(const double *X, size_t n, int dim, size_t ld, double *o, hipStream_t s) {
         return launch_cosine_norms_f64(X, n, dim, ld, o, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os,
-                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s) {
+                             size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s,
+                             const uint32_t * = nullptr) {
         return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s);
     }
 };
@@ -821,7 +835,10 @@ template <> struct Ops<double> {
 template <typename T>
 static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t nq_pad, int dim_eff, size_t kout,
                      uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s, bool second_tier,
-                     const uint32_t *nq_dev, uint32_t nq_off, CallRec *rec, const T *qnorm = nullptr) {
+                     const uint32_t *nq_dev, uint32_t nq_off, CallRec *rec, const T *qnorm = nullptr,
+                     const uint32_t *rowsel = nullptr) {
+    // rowsel (second tier): query r of this round is row rowsel[nq_off + r] of Qp AND of the outputs -- the flagged
+    // queries are scanned and answered in place (no gather / scatter launches)
     using KeyT = typename KeyOf<T>::type;
     // k beyond one candidate buffer (960 slots): rounds of <= 960 neighbours, each resuming strictly
     // after the last (distance key, row) of the previous one
@@ -856,34 +873,34 @@ static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, 
         const size_t kr = kout - done < kRound ? kout - done : kRound;
         HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, dim_eff, ix->ld, Qp, (int)nq, ix->ld, (int)kr, pl.seg_len, cb,
                            done ? lo_key : nullptr, done ? lo_idx : nullptr, nq_dev, nq_off,
-                           qnorm ? (const T *)ix->d_cnorm : nullptr, qnorm, s));
+                           qnorm ? (const T *)ix->d_cnorm : nullptr, qnorm, s, rowsel));
         if (prof && done == 0) HIPCHK(hipEventRecord(rec->ev[1], s));
         HIPCHK(Ops<T>::select(cb, (int)nq, (int)kr, ix->index_base, d_idx, d_dist, out_stride, done, lo_key, lo_idx,
-                              nq_dev, nq_off, qnorm != nullptr, s));
+                              nq_dev, nq_off, qnorm != nullptr, s, rowsel));
     }
     return PN_OK;
 }
 
-// Second tier behind a filter tier: the queries whose exclusions the re-rank could not prove (flags, counted in
-// *d_nflag on the device) are listed, gathered, answered by the exact engine and scattered back -- all of it enqueued
-// unconditionally and driven by the device-side count, so the host never waits to learn whether anything was flagged
-// (with nothing flagged every kernel here exits at once).  Rounds of kSecondTierRows queries bound the scratch.
+// Second tier behind a filter tier: the queries whose exclusions the re-rank could not prove -- LISTED by the re-rank
+// kernel itself (d_sel[0 .. *d_nsel), the count stays on the device) -- are answered by the exact engine, all of it
+// enqueued unconditionally and driven by the device-side count, so the host never waits to learn whether anything was
+// flagged.  The flagged queries are read and answered IN PLACE through the list (round 2 listed them, gathered their
+// rows, scanned, selected and scattered with a launch each: twelve empty launches, ~55 us, behind every batch; now
+// five).  Rounds of kSecondTierRows queries bound the scratch.  h_count (nullable, mapped pinned memory): the count
+// is left there for a LATER call to look at; returns *count_published = true when a kernel here does that.
 constexpr size_t kSecondTierRows = 16384;
 constexpr size_t kSecondTierFew = 256;  // the first flagged queries of a chunk take the many-segment path below
 static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kout,
-                             const uint32_t *d_flags, uint32_t *d_nsel, uint64_t *d_idx, float *d_dist,
-                             size_t out_stride, hipStream_t s) {
+                             const uint32_t *d_sel, const uint32_t *d_nsel, uint64_t *d_idx, float *d_dist,
+                             size_t out_stride, hipStream_t s, uint32_t *h_count, bool *count_published) {
     const size_t F = nq < kSecondTierRows ? nq : kSecondTierRows, F_pad = round_up(F, (size_t)256);
-    PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
-    PNCHK(ws.w_gq.ensure(F_pad * ix->ld * sizeof(float)));  // rows beyond the count are never read as queries
-    PNCHK(ws.w_gidx.ensure(F * kout * sizeof(uint64_t)));
-    PNCHK(ws.w_gdist.ensure(F * kout * sizeof(float)));
-    HIPCHK(launch_compact_flags(d_flags, (int)nq, (uint32_t *)ws.w_gsel.p, d_nsel, s));
+    *count_published = false;
     size_t first = 0;
     // Few flagged queries are the normal case, and they share ONE 64-query tile: with the usual <= 32 segments that is
     // <= 32 workgroups for the whole corpus (10M rows: 0.4 s for a single flagged query).  So the first 256 flagged
     // queries of a chunk are scanned with up to 512 row segments -- every CU busy -- and selected in two levels:
-    // groups of 16 segments to a part each, then the (distance, index) merge of the parts (the shard-merge kernel).
+    // groups of 16 segments to a part each, then the (distance, index) merge of the parts (the shard-merge kernel),
+    // which writes each answer straight to its query's row.
     const size_t by_rows = (ix->n + 4095) / 4096;
     if (kout <= 192 && by_rows >= 16) {
         const size_t Ff = nq < kSecondTierFew ? nq : kSecondTierFew, Ff_pad = kSecondTierFew;
@@ -902,29 +919,22 @@ static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp,
         uint64_t *p_idx = (uint64_t *)ws.w_fparts.p;
         float *p_dist = (float *)(p_idx + groups * Ff_pad * kout);
         CandBuf cb{ws.w2_keys.p, (uint32_t *)ws.w2_idx.p, (uint32_t *)ws.w2_cnt.p, ws.w2_tau.p, Ff_pad, (int)nseg, cap};
-        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, d_nsel, 0, (uint32_t)Ff, (float *)ws.w_gq.p, s));
-        HIPCHK(launch_exact_knn_f32((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, (const float *)ws.w_gq.p, (int)Ff,
-                                    ix->ld, (int)kout, seg_len, cb, nullptr, nullptr, d_nsel, 0, nullptr, nullptr, s));
+        HIPCHK(launch_exact_knn_f32((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)Ff, ix->ld, (int)kout,
+                                    seg_len, cb, nullptr, nullptr, d_nsel, 0, nullptr, nullptr, s, d_sel));
         CandBuf cg = cb;
         cg.nseg = 16;
+        // (index_base is added by the group selection; the merge orders the parts' GLOBAL indices)
         HIPCHK(launch_select_exact_groups_f32(cg, (int)groups, (int)kout, (int)Ff, (int)kout, ix->index_base, p_idx, p_dist,
                                               Ff_pad * kout, d_nsel, 0, s));
         HIPCHK(launch_merge_topk_f32(p_idx, p_dist, (int)groups, Ff_pad * kout, Ff_pad * kout, (int)Ff, (int)kout, (int)kout,
-                                     (uint64_t *)ws.w_gidx.p, (float *)ws.w_gdist.p, s, d_nsel));
-        HIPCHK(launch_scatter_results_f32((const uint64_t *)ws.w_gidx.p, (const float *)ws.w_gdist.p,
-                                          (const uint32_t *)ws.w_gsel.p, d_nsel, 0, (uint32_t)Ff, (int)kout, d_idx, d_dist,
-                                          out_stride, s));
+                                     d_idx, d_dist, s, d_nsel, d_sel, out_stride, h_count));
+        *count_published = h_count != nullptr;
         first = Ff;
     }
     for (size_t off = first; off < nq; off += F) {
         const size_t fr = nq - off < F ? nq - off : F;
-        HIPCHK(launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, d_nsel, (uint32_t)off, (uint32_t)fr,
-                                      (float *)ws.w_gq.p, s));
-        PNCHK(run_exact<float>(ix, ws, (const float *)ws.w_gq.p, fr, F_pad, (int)ix->dim, kout, (uint64_t *)ws.w_gidx.p,
-                               (float *)ws.w_gdist.p, kout, s, true, d_nsel, (uint32_t)off, nullptr));
-        HIPCHK(launch_scatter_results_f32((const uint64_t *)ws.w_gidx.p, (const float *)ws.w_gdist.p,
-                                          (const uint32_t *)ws.w_gsel.p, d_nsel, (uint32_t)off, (uint32_t)fr, (int)kout,
-                                          d_idx, d_dist, out_stride, s));
+        PNCHK(run_exact<float>(ix, ws, Qp, fr, F_pad, (int)ix->dim, kout, d_idx, d_dist, out_stride, s, true, d_nsel,
+                               (uint32_t)off, nullptr, nullptr, d_sel));
     }
     return PN_OK;
 }
@@ -961,6 +971,7 @@ struct Bf16Plan {
     int per_tile;
     // shared thresholds (bf16_filter.hip): refresher workgroups behind the n_wg main ones, rank of the shared threshold
     int n_refresh, sh_rank;
+    int first_eval;  // candidates the re-rank evaluates in its first round (the plan's R, rounded up)
 };
 // Wide rows: one workgroup per CU at a time (128 KiB of LDS), a whole number of workgroups per query tile: every cell
 // then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
@@ -1045,6 +1056,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
         }
     }
 #endif
+    p.first_eval = (int)std::ceil(R);
     return p;
 }
 // Narrow rows, enough work for every workgroup slot: a grid of c workgroups per query tile, run in rounds when it
@@ -1160,6 +1172,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // heavier-tailed than Poisson); a query with r or more of them only goes to the next tier.  Measured over 10^6
     // queries (tools/sh_fallback_rate.py): unproven queries 4 without shared thresholds (a segment's k' overflows),
     // 4 at r = 56 .. 80, 5 at r = 48; r = 40: 5 10^-5, r = 32: 3 10^-3.
+    p.first_eval = (int)std::ceil(R);
     p.n_refresh = 0;
     p.sh_rank = 0;
     if (p.shared_scout && p.aligned && ix->shared_tau != 0 && bf16_shared_supported(p.cap)) {
@@ -1218,7 +1231,7 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
     PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
     PNCHK(ws.w_tau.ensure(cells * sizeof(uint32_t)));
     PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ws.w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
+    PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));  // the re-rank lists the queries it could not prove here
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_idx.p, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, plan.nseg, cap};
     if (v2) {  // not every (segment, query tile) cell is written by the persistent partition
         HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -1243,13 +1256,16 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
     if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,
-                                    d_misc, nullptr, nullptr, (uint32_t *)ws.w_qstat.p, ix->d_stats, s));
+                                    d_misc, nullptr, nullptr, (uint32_t *)ws.w_gsel.p, ix->d_stats, s));
     return PN_OK;
 }
 
 // bf16 filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for the unproven queries
+// d_q_raw (nullable; narrow rows): the caller's queries, row stride q_stride -- Qp has NOT been filled and the call's
+// counters have not been zeroed yet: the query pack kernel does both on the way (one launch at the head of the call)
 static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, const float *Qp, size_t nq, size_t nq_pad,
-                    size_t kout, uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s, CallRec *rec) {
+                    size_t kout, uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s, CallRec *rec,
+                    const float *d_q_raw = nullptr, size_t q_stride = 0) {
     if (!plan.ok) return fail(PN_ERR_UNSUPPORTED, "bf16 tier cannot serve k = %zu", kout);
     const int n_wg = plan.n_wg, cap = plan.cap, nseg = plan.nseg;
     const size_t kp = (size_t)plan.kp;
@@ -1261,10 +1277,15 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     PNCHK(ws.w_cnt.ensure(cells * sizeof(uint32_t)));
     PNCHK(ws.w_tau.ensure(cells * sizeof(uint32_t)));
     PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
-    PNCHK(ws.w_qstat.ensure(nq_pad * 2 * sizeof(uint32_t)));
+    PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));  // the re-rank lists the queries it could not prove here
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
-    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                    (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
+    if (d_q_raw)
+        HIPCHK(launch_bf16_pack_queries(d_q_raw, ix->d_mu, nq, nq_pad, (int)ix->dim, q_stride, ws.w_bq.p,
+                                        (double *)ws.w_qn.p, (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax,
+                                        ix->bf16_dmax, s, const_cast<float *>(Qp), ix->ld, d_misc));
+    else
+        HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
+                                        (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_keys.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
     if (!plan.aligned) {  // cells without a writer must read "empty" (an aligned partition writes every cell)
         HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
@@ -1288,9 +1309,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
         else
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
                                       nullptr, false, (float *)ws.w_lists.p, ix->bf16_ci, s));
-        if (prof) HIPCHK(hipEventRecord(rec->ev[4], s));
         HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s));
-        if (prof) HIPCHK(hipEventRecord(rec->ev[5], s));
         if (plan.wide)
             HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg, 0,
                                            (const uint32_t *)ws.w_seed.p, false, nullptr, s));
@@ -1323,7 +1342,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,
                                     d_misc, (const double *)ws.w_qn.p, (const uint32_t *)ws.w_qbad.p,
-                                    (uint32_t *)ws.w_qstat.p, ix->d_stats, s));
+                                    (uint32_t *)ws.w_gsel.p, ix->d_stats, s, plan.first_eval, bf16_cell_max((int)kp, cap)));
     return PN_OK;
 }
 
@@ -1351,10 +1370,9 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
         PNCHK(rec_begin(ix, call_id, nqc, &rec));
         RecGuard rec_guard(ix);
         rec_guard.r = rec;  // released on every early return below; rec_end takes over on success
-        if (rec->prof) HIPCHK(hipEventRecord(rec->ev[2], s));
+        if (rec->prof > 1) HIPCHK(hipEventRecord(rec->ev[2], s));
         PNCHK(ws.w_q.ensure(nq_pad * ix->ld * sizeof(T)));
         T *Qp = (T *)ws.w_q.p;
-        HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
         uint64_t *oi = d_idx + qs * out_stride;
         T *od = d_dist + qs * out_stride;
         bool use_mfma = false, use_bf16 = false;
@@ -1378,25 +1396,37 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
                 bplan = bf16_plan(ix, nq_pad, kout, level);
                 use_bf16 = bplan.ok;
             }
+        }
+        // the head of the call: the zero-padded copy of the queries (+ the call's counters, zeroed) -- for narrow rows
+        // on the bf16 tier both are by-products of the tier's own query pack kernel (run_bf16)
+        bool fused_head = false;
+        if constexpr (sizeof(T) == 4) fused_head = use_bf16 && !bplan.wide && bf16_pack_fused_supported((int)ix->dim);
+        if (!fused_head) HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
+        if constexpr (sizeof(T) == 4) {
             if (use_bf16 || use_mfma) {
                 PNCHK(ws.w_misc.ensure(64));
-                HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
+                if (!fused_head) HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
                 uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
                 if (use_bf16)
-                    PNCHK(run_bf16(ix, ws, bplan, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
+                    PNCHK(run_bf16(ix, ws, bplan, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec,
+                                   fused_head ? (const float *)(d_q + qs * q_stride) : nullptr, q_stride));
                 else
                     PNCHK(run_mfma(ix, ws, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
-                PNCHK(second_tier_exact(ix, ws, (const float *)Qp, nqc, kout, (const uint32_t *)ws.w_flags.p, d_misc + 4, oi,
-                                        (float *)od, out_stride, s));
-                // the flagged count travels to pinned memory behind everything else; a LATER call looks at it
-                HIPCHK(hipMemcpyAsync(rec->h_nflag, d_misc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                // the flagged count reaches pinned memory behind everything else (written by the second tier's merge
+                // kernel, else by a copy); a LATER call looks at it
+                uint32_t *h_dev = nullptr;
+                if (hipHostGetDevicePointer((void **)&h_dev, rec->h_nflag, 0) != hipSuccess) h_dev = nullptr;
+                bool published = false;
+                PNCHK(second_tier_exact(ix, ws, (const float *)Qp, nqc, kout, (const uint32_t *)ws.w_gsel.p, d_misc, oi,
+                                        (float *)od, out_stride, s, h_dev, &published));
+                if (!published) HIPCHK(hipMemcpyAsync(rec->h_nflag, d_misc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 rec->has_flag = true;
                 rec->bf16_tier = use_bf16;
             }
         }
         if (!use_bf16 && !use_mfma)
             PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec, qnorm));
-        if (rec->prof) HIPCHK(hipEventRecord(rec->ev[3], s));
+        if (rec->prof > 1) HIPCHK(hipEventRecord(rec->ev[3], s));
         rec_guard.r = nullptr;
         PNCHK(rec_end(ix, rec, s));
     }
@@ -1834,18 +1864,38 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
     HIPCHK(launch_compact_flags((const uint32_t *)ws.w_qbad.p, (int)nq, (uint32_t *)ws.w_gsel.p, d_misc + 1, s));
     HIPCHK(launch_bf16_radius_tau((const double *)ws.w_qn.p, nq_pad, t, (uint32_t *)ws.w_seed.p, s));
     CandBuf cb{ws.w_idx.p, (uint32_t *)ws.w_idx.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
+    // PN_OPT_PROFILE: the filter launch between two events of the workspace (the radius entry points wait for their
+    // stream anyway: the bracket is resolved in radius_finish's shadow, below)
+    const bool prof = ix->profile != 0;
+    if (prof) {
+        if (!ws.ev_r[0]) {
+            HIPCHK(hipEventCreate(&ws.ev_r[0]));
+            HIPCHK(hipEventCreate(&ws.ev_r[1]));
+        }
+        HIPCHK(hipEventRecord(ws.ev_r[0], s));
+    }
     if (wide)
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, wide_wg, 0,
                                        (const uint32_t *)ws.w_seed.p, true, nullptr, s));
     else
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
                                   (const uint32_t *)ws.w_seed.p, true, nullptr, ix->bf16_ci, s));
+    if (prof) HIPCHK(hipEventRecord(ws.ev_r[1], s));
     HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                    (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
                                    (uint32_t *)ws.w_sel.p, s));
-    return radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets, idx_out, done,
-                         s);
+    const int rc = radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets, idx_out,
+                                 done, s);
+    if (prof && rc == PN_OK) {  // (radius_finish has waited for the stream)
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ws.ev_r[0], ws.ev_r[1]) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(ix->sh.mu);
+            ix->sh.stats.hot_ms += ms;
+            ix->sh.stats.hot_launches += 1;
+        }
+    }
+    return rc;
 }
 
 static int radius_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,

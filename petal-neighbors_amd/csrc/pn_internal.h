@@ -69,10 +69,12 @@ inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 // nq_dev (nullable) / nq_off: device-driven query count -- only the first min(nq, max(*nq_dev - nq_off, 0)) queries
 // exist; the grid is sized for nq and the surplus query tiles exit at once (second tier behind a filter)
 // pnorm / qnorm (nullable, together): the index's metric is Cosine -- distance = 1 - dot / (qnorm[q] pnorm[row])
+// qsel (nullable, f32 Euclidean only): query r of the launch is row qsel[nq_off + r] of Q -- the flagged queries of a
+// filter tier read in place (no gather launch)
 hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                 const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const float *pnorm,
-                                const float *qnorm, hipStream_t s);
+                                const float *qnorm, hipStream_t s, const uint32_t *qsel = nullptr);
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                 const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const double *pnorm,
@@ -101,10 +103,11 @@ hipError_t launch_cosine_pairwise_f64(const double *X, size_t n, int dim, size_t
 // Exact mode: keys are exact distance keys; picks the kout smallest (key, idx).
 // writes results r < kout of query q at [q * out_stride + out_off + r]; when lo_key != nullptr also
 // records the last (key, row) written per query as the next round's lower bound
+// osel (nullable): the results of query q go to output row osel[nq_off + q] instead of row q (scatter in place)
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                   hipStream_t s);
+                                   hipStream_t s, const uint32_t *osel = nullptr);
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
@@ -118,16 +121,24 @@ hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp,
 // qn / qbad (nullable, [nq]): the thresholds bound |q-p|^2 - |q|^2 (bf16 filter), qn[q] <= |q|^2 is added back;
 // qbad[q] != 0 flags the query outright
 // results of query q go to idx_out/dist_out[q * out_stride + r]; n_flagged: per-call count of flagged queries (device,
-// zeroed by the caller); stats (nullable): the index's running device counters {fallback queries, candidates, exact
-// evaluations}, added to from qstat (scratch [2 * nq]) and n_flagged by a one-block kernel behind the re-rank
+// zeroed by the caller); sel (nullable, [nq]): the flagged queries are LISTED here as they are found (sel[0 ..
+// *n_flagged), any order) -- the second tier's work list, no listing launch; stats (nullable): the index's running
+// device counters, kPnStatWords words: [0] fallback queries, then kPnStatSlots pairs {candidates, exact evaluations}
+// that the queries add to by q mod kPnStatSlots (10^4 waves adding to ONE address cost as much as the whole kernel)
+constexpr int kPnStatSlots = 64, kPnStatWords = 4 + 2 * kPnStatSlots;
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
-                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *qstat,
-                                    unsigned long long *stats, hipStream_t s);
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
+                                    unsigned long long *stats, hipStream_t s, int first_eval = 0, int cell_max = 0);
+// first_eval: candidates (smallest bounds first) evaluated in the first round, >= kout (0: kout); cell_max: entries a
+// (segment, query) cell holds at most (0: cb.cap) -- sizes the kernel's LDS
+// osel (nullable): the merged result of query q goes to row osel[q] of the outputs (row stride out_stride, 0 = k_out);
+// host_count (nullable, mapped pinned memory): block 0 copies *nq_dev there (the count a LATER call looks at)
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
-                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr);
+                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
+                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
 // gather rows sel[off + i] of src into dst row i / scatter result rows i back to query sel[off + i], for
 // i < min(max_rows, *nsel - off): the count stays on the device
 hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
@@ -202,9 +213,13 @@ hipError_t launch_bf16_row_stats(const float *P, const float *mu, size_t n, int 
                                  hipStream_t s);
 hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
                                    uint32_t *bad, bool ci, hipStream_t s);
+// Qp / ldq / misc (nullable, narrow rows only: bf16_pack_fused_supported): Q is the CALLER's array (row stride ld); the
+// kernel also writes the zero-padded f32 copy Qp[nq_pad][ldq] and zeroes the 16 counter words at misc -- the three
+// launches at the head of a call in one
+bool bf16_pack_fused_supported(int dim);
 hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s);
+                                    hipStream_t s, float *Qp = nullptr, size_t ldq = 0, uint32_t *misc = nullptr);
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);
@@ -235,6 +250,7 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
                                    int n_wg, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                                    hipStream_t s);
 int bf16_scout_list();
+int bf16_cell_max(int kp, int cap);  // entries a cell holds at most after a k-NN launch (its final cut to k')
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);
 hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
                                                           typename KeyOf<T>::type *__restrict__ lo_key,
                                                           uint32_t *__restrict__ lo_idx,
                                                           const uint32_t *__restrict__ nq_dev, uint32_t nq_off,
-                                                          int signed_keys, size_t out_group_stride) {
+                                                          int signed_keys, size_t out_group_stride,
+                                                          const uint32_t *__restrict__ osel) {
     using KeyT = typename KeyOf<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         const uint32_t tot = *nq_dev;
         if (q >= (size_t)(tot > nq_off ? tot - nq_off : 0u)) return;
     }
+    const size_t qo = osel ? (size_t)osel[nq_off + q] : q;  // output row (second tier: the flagged query's own row)
     // blockIdx.y = segment group (two-level selection over many segments): group g selects among segments
     // [g nseg, (g+1) nseg) into its own output part
     ckey += (size_t)blockIdx.y * (size_t)nseg * nq_pad * (size_t)cap;
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         const uint32_t ix = sidx[e];
         const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
-            idx_out[q * out_stride + out_off + r] = index_base + ix;
-            dist_out[q * out_stride + out_off + r] = signed_keys ? key_to_dist_signed(k) : key_to_dist(k);
+            idx_out[qo * out_stride + out_off + r] = index_base + ix;
+            dist_out[qo * out_stride + out_off + r] = signed_keys ? key_to_dist_signed(k) : key_to_dist(k);
             if (lo_key && r == (uint32_t)kout - 1) {  // next round resumes strictly after this entry
                 lo_key[q] = k;
                 lo_idx[q] = ix;
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const typename KeyOf<T
         }
     }
     for (uint32_t r = n_all + lane; r < (uint32_t)kout; r += 64) {  // cannot happen for kout = min(k, n_points)
-        idx_out[q * out_stride + out_off + r] = ~0ull;
-        dist_out[q * out_stride + out_off + r] = key_to_dist(KeyOf<T>::kNaN);
+        idx_out[qo * out_stride + out_off + r] = ~0ull;
+        dist_out[qo * out_stride + out_off + r] = key_to_dist(KeyOf<T>::kNaN);
     }
 }
 
@@ -172,7 +174,8 @@ template <typename T>
 static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                       T *dist_out, int kp_bound, size_t out_stride, size_t out_off, void *lo_key,
                                       uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                      hipStream_t s, int groups = 1, size_t out_group_stride = 0) {
+                                      hipStream_t s, int groups = 1, size_t out_group_stride = 0,
+                                      const uint32_t *osel = nullptr) {
     using KeyT = typename KeyOf<T>::type;
     // cb.nseg = segments per group; every cell holds at most kp_bound entries
     const size_t sh = (size_t)cb.nseg * (size_t)kp_bound * (sizeof(KeyT) + sizeof(uint32_t));
@@ -180,7 +183,7 @@ static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint6
     hipLaunchKernelGGL((select_exact_kernel<T>), dim3((unsigned)nq, (unsigned)groups), dim3(64), sh, s,
                        static_cast<const KeyT *>(cb.keys), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, kout,
                        index_base, idx_out, dist_out, out_stride, out_off, static_cast<KeyT *>(lo_key), lo_idx, nq_dev,
-                       nq_off, signed_keys ? 1 : 0, out_group_stride);
+                       nq_off, signed_keys ? 1 : 0, out_group_stride, osel);
     return hipGetLastError();
 }
 // two-level selection, first level: `groups` groups of cb.nseg segments each (cb describes group 0, the groups follow
@@ -195,9 +198,9 @@ hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp,
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                   hipStream_t s) {
+                                   hipStream_t s, const uint32_t *osel) {
     return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                      lo_key, lo_idx, nq_dev, nq_off, signed_keys, s);
+                                      lo_key, lo_idx, nq_dev, nq_off, signed_keys, s, 1, 0, osel);
 }
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
@@ -309,18 +312,46 @@ __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t
     return T;
 }
 
+#ifdef PN_DIAG_RR_STAMP  // diagnostic build only: where a re-rank wave's time goes (cycle sums per phase)
+// per-query phase durations [16384][8], written once per wave at its end (an atomic per phase on a shared counter
+// would itself be what the waves wait for)
+__device__ uint32_t g_rrdbg[16384 * 8];
+#define RR_STAMP(i)                                                                   \
+    do {                                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
+        rr_d_[i] = (uint32_t)(t_ - rr_t_);                                            \
+        rr_t_ = t_;                                                                   \
+    } while (0)
+extern "C" int pn_debug_read_rr(unsigned long long *out, int nq) {
+    static uint32_t h[16384 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rrdbg), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int q = 0; q < nq && q < 16384; ++q)
+        for (int i = 0; i < 8; ++i) out[i] += h[q * 8 + i];
+    return 0;
+}
+#else
+#define RR_STAMP(i) ((void)0)
+#endif
 __global__ __launch_bounds__(64) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
     size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
     float *__restrict__ dist_out, size_t out_stride, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
     const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
-    int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ qstat) {
+    int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ sel,
+    unsigned long long *__restrict__ stats, uint32_t first_eval) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t kth_key;
     __shared__ uint32_t seg_off[65], seg_cnt[64];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+#ifdef PN_DIAG_RR_STAMP
+    unsigned long long rr_t_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t rr_d_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // Gather phase with few dependent memory round trips (a wave per query spends its time waiting, not computing):
     // the lanes read the cells' counts and thresholds side by side, a wave scan turns the counts into offsets, and
     // every lane then finds the cell of "its" candidate by itself -- instead of walking the cells one after another.
@@ -340,6 +371,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         total_cap += a;
     }
     const float min_tau = __uint_as_float((min_key & 0x80000000u) ? (min_key & 0x7FFFFFFFu) : ~min_key);
+    RR_STAMP(0);  // counts + thresholds read and reduced
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sidx = skey + total_cap;
     uint32_t *sfk = sidx + total_cap;  // the filter's keys (when given)
@@ -415,6 +447,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         }
         n += chunk_total;
     }
+    RR_STAMP(1);  // candidates gathered into LDS
     if (!ckey) {
         evaluated = n;
     } else {
@@ -422,10 +455,15 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         // candidates never need their exact distance: evaluate the kout with the smallest bounds, take the kout-th
         // exact distance d among them, and evaluate further only the candidates whose bound does not PROVE them
         // farther than d (same inequality as the proof below).  Unevaluated entries keep the key 0xFFFFFFFF.
+        // (round 2: the first round takes the first_eval >= kout smallest bounds -- the plan's estimate of how many
+        // candidates need their distance anyway (C2: 24 of 136; 22.8 were evaluated in two rounds before) -- so that the
+        // second round, a second pair of dependent memory round trips, is empty for most queries)
         __syncthreads();
-        bool all = n <= (uint32_t)kout;
+        const uint32_t m1 = first_eval > (uint32_t)kout ? first_eval : (uint32_t)kout;
+        bool all = n <= m1;
         uint32_t K1 = 0xFFFFFFFFu;
-        if (!all) K1 = kth_smallest_lds(sfk, n, (uint32_t)kout, lane);
+        if (!all) K1 = kth_smallest_lds(sfk, n, m1, lane);
+        RR_STAMP(2);  // k-th smallest bound
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             const bool go = e < n && (all || sfk[e] <= K1);
@@ -436,8 +474,10 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
             evaluated += (uint32_t)__popcll(__ballot(go));
         }
         __syncthreads();
+        RR_STAMP(3);  // first evaluation round
         if (!all) {
             const uint32_t dk1 = kth_smallest_lds(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
+            RR_STAMP(4);  // k-th smallest exact distance so far
             const bool prune = dk1 < 0x7F800000u;  // finite: else every candidate is evaluated
             double rhs = 0.0;
             if (prune) {
@@ -464,9 +504,31 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         }
     }
     __syncthreads();
+    RR_STAMP(5);  // second evaluation round
     const uint32_t n_all = n;
+    if (ckey) {
+        // only evaluated candidates can be among the answers: move them to the front (stable, in place: a chunk's
+        // writes land at or below what it has just read), so that selection and ranking run over ~2k entries, not n
+        uint32_t w = 0;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const uint32_t k = e < n ? skey[e] : 0xFFFFFFFFu;
+            const uint32_t ix = e < n ? sidx[e] : 0u;
+            const bool keep = k != 0xFFFFFFFFu;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                skey[pos] = k;
+                sidx[pos] = ix;
+            }
+            w += (uint32_t)__popcll(m);
+        }
+        n = w;
+        __syncthreads();
+    }
     n = prune_to_topk<uint32_t, uint32_t>(skey, sidx, n, (uint32_t)kout, lane);
     __syncthreads();
+    RR_STAMP(6);  // cut to the k smallest
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t k = skey[e];
         const uint32_t ix = sidx[e];
@@ -478,6 +540,15 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         }
     }
     __syncthreads();
+    RR_STAMP(7);  // ranked and written
+#ifdef PN_DIAG_RR_STAMP
+    if (lane < 8 && q < 16384) {
+        uint32_t v_ = 0;
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) v_ = lane == i_ ? rr_d_[i_] : v_;
+        g_rrdbg[q * 8 + lane] = v_;
+    }
+#endif
     if (lane == 0) {
         bool ok = n_all >= (uint32_t)kout;
         const uint32_t kk = kth_key;
@@ -496,51 +567,37 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         }
         if (qbad && qbad[q]) ok = false;
         flags[q] = ok ? 0u : 1u;
-        if (!ok) atomicAdd(n_flagged, 1u);
-        // statistics: per-query words, summed by stat_reduce_kernel (10^4 blocks adding to one address took as
-        // long as everything else in this kernel together)
-        if (qstat) {
-            qstat[2 * q] = n_all;
-            qstat[2 * q + 1] = evaluated;
+        if (!ok) {  // the second tier's work list is built here (any order: answers go back by query number)
+            const uint32_t slot = atomicAdd(n_flagged, 1u);
+            if (sel) sel[slot] = (uint32_t)q;
+            if (stats) atomicAdd(stats, 1ull);
+        }
+        // statistics: kPnStatSlots pairs of running counters, a query adds to pair q mod kPnStatSlots (10^4 waves
+        // adding to ONE address took as long as everything else in this kernel together); the host sums the pairs
+        if (stats) {
+            unsigned long long *sp = stats + 4 + 2 * (q % (size_t)kPnStatSlots);
+            atomicAdd(sp, (unsigned long long)n_all);
+            atomicAdd(sp + 1, (unsigned long long)evaluated);
         }
     }
-}
-
-// stats[0] += flagged queries of this call, stats[1] += candidates, stats[2] += exact evaluations (the index's
-// running device counters: the host reads them only when statistics are asked for)
-__global__ void stat_reduce_kernel(const uint32_t *__restrict__ qstat, int nq, const uint32_t *__restrict__ n_flagged,
-                                   unsigned long long *__restrict__ stats) {
-    unsigned long long a = 0, b = 0;
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-        a += qstat[2 * i];
-        b += qstat[2 * i + 1];
-    }
-    for (int d = 32; d > 0; d >>= 1) {
-        a += __shfl_xor(a, d);
-        b += __shfl_xor(b, d);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(stats + 1, a);
-        atomicAdd(stats + 2, b);
-    }
-    if (threadIdx.x == 0 && n_flagged) atomicAdd(stats, (unsigned long long)*n_flagged);
 }
 
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
                                     const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
                                     uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
-                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *qstat,
-                                    unsigned long long *stats, hipStream_t s) {
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
+                                    unsigned long long *stats, hipStream_t s, int first_eval, int cell_max) {
     // with filter keys in the buffers (both MFMA tiers) candidates are evaluated lazily
     const uint32_t *ckey = static_cast<const uint32_t *>(cb.keys);
-    const size_t sh = (size_t)cb.nseg * (size_t)cb.cap * 12 + ((size_t)dim + 8) * sizeof(float);
+    // LDS for what the cells can HOLD (cell_max entries each: the filter's k' after its final cut), not for their
+    // capacity: C2 12 x 13 entries = 1.9 KB instead of 9.2 KB, and the waves per CU are no longer set by LDS
+    const size_t per_cell = cell_max > 0 && cell_max < cb.cap ? (size_t)cell_max : (size_t)cb.cap;
+    const size_t sh = (size_t)cb.nseg * per_cell * 12 + ((size_t)dim + 8) * sizeof(float);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
                        ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, out_stride, flags, n_flagged, qn,
-                       qbad, cb.idx_stride, ckey, qstat);
-    if (qstat && stats)
-        hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(1024), 0, s, qstat, nq, n_flagged, stats);
+                       qbad, cb.idx_stride, ckey, sel, stats, (uint32_t)(first_eval > 0 ? first_eval : 0));
     return hipGetLastError();
 }
 
@@ -624,11 +681,17 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
                                                         size_t idx_part_stride, size_t dist_part_stride, int nq,
                                                         int k_part, int k_out, uint64_t *__restrict__ idx_out,
                                                         float *__restrict__ dist_out,
-                                                        const uint32_t *__restrict__ nq_dev) {
+                                                        const uint32_t *__restrict__ nq_dev,
+                                                        const uint32_t *__restrict__ osel, size_t out_stride,
+                                                        uint32_t *__restrict__ host_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+    // the flagged-query count of this chunk goes to pinned host memory from here (a LATER call looks at it): no copy
+    // command, whose completion signal cost the stream ~25 us
+    if (host_count && q == 0 && lane == 0) *host_count = nq_dev ? *nq_dev : 0u;
     if (nq_dev && q >= (size_t)*nq_dev) return;  // device-driven query count (second tier, index.hip)
+    const size_t qo = osel ? (size_t)osel[q] : q;  // output row
     uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
     uint64_t *sidx = reinterpret_cast<uint64_t *>(smem);
     uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
@@ -651,14 +714,14 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
         if (k == KeyOf<float>::kMax) continue;
         const uint32_t r = rank_of<uint32_t, uint64_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)k_out) {
-            idx_out[q * k_out + r] = ix;
-            dist_out[q * k_out + r] = key_to_dist(k);
+            idx_out[qo * out_stride + r] = ix;
+            dist_out[qo * out_stride + r] = key_to_dist(k);
         }
     }
     // absent tail (fewer than k_out valid entries over all parts)
     for (uint32_t r = n_valid + lane; r < (uint32_t)k_out; r += 64) {
-        idx_out[q * k_out + r] = ~0ull;
-        dist_out[q * k_out + r] = key_to_dist(KeyOf<float>::kNaN);
+        idx_out[qo * out_stride + r] = ~0ull;
+        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<float>::kNaN);
     }
 }
 
@@ -674,10 +737,14 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
                                                                int nq, int k_part, int k_out,
                                                                uint64_t *__restrict__ idx_out,
                                                                float *__restrict__ dist_out,
-                                                               const uint32_t *__restrict__ nq_dev) {
+                                                               const uint32_t *__restrict__ nq_dev,
+                                                               const uint32_t *__restrict__ osel, size_t out_stride,
+                                                               uint32_t *__restrict__ host_count) {
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+    if (host_count && q == 0 && lane == 0) *host_count = nq_dev ? *nq_dev : 0u;
     if (nq_dev && q >= (size_t)*nq_dev) return;
+    const size_t qo = osel ? (size_t)osel[q] : q;
     const uint32_t kp = (uint32_t)k_part, ko = (uint32_t)k_out;
     const uint32_t lim = kp < ko ? kp : ko;  // positions of a part that can reach the output
     uint32_t n_valid = 0;
@@ -711,28 +778,32 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
                 rank += a;
             }
             if (rank < ko) {
-                idx_out[q * ko + rank] = ix;
-                dist_out[q * ko + rank] = key_to_dist(key);
+                idx_out[qo * out_stride + rank] = ix;
+                dist_out[qo * out_stride + rank] = key_to_dist(key);
             }
         }
     }
     for (uint32_t r = n_valid + (uint32_t)lane; r < ko; r += 64) {  // absent tail
-        idx_out[q * ko + r] = ~0ull;
-        dist_out[q * ko + r] = key_to_dist(KeyOf<float>::kNaN);
+        idx_out[qo * out_stride + r] = ~0ull;
+        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<float>::kNaN);
     }
 }
 
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
-                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev) {
+                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev,
+                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
     const size_t sh = (size_t)n_parts * k_part * 12;
+    if (out_stride == 0) out_stride = (size_t)k_out;
     if (sh > 64 * 1024) {  // beyond the LDS-resident merge: the rank-by-binary-search merge of sorted parts
         hipLaunchKernelGGL(merge_sorted_topk_kernel, dim3((unsigned)nq), dim3(64), 0, s, idx_parts, dist_parts, n_parts,
-                           idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev);
+                           idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel,
+                           out_stride, host_count);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
-                       idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev);
+                       idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel, out_stride,
+                       host_count);
     return hipGetLastError();
 }
 

@@ -180,6 +180,13 @@ struct Dev {  // one GPU this process drives = one rank of the communicator
     hipStream_t last_stream = nullptr;
     bool in_flight = false;
     std::vector<void *> retired;
+    // PN_OPT_PROFILE: per call three timing events (start, local half done, merged) in a ring, resolved when a slot
+    // is reused and by pn_sharded_get_stats -- never inside a call
+    static constexpr int kProf = 32;
+    hipEvent_t ev_prof[kProf][3] = {};
+    bool prof_pending[kProf] = {};
+    unsigned prof_next = 0;
+    double shard_ms = 0.0, exchange_ms = 0.0;
     // (Bufs point at this Dev's retired list: adopt() after the vector of Devs has its final size)
     void adopt() {
         Buf *bs[] = {&q, &out_idx, &out_dist, &lparts, &pack[0], &pack[1], &gathered[0], &gathered[1], &rad_a, &rad_b};
@@ -204,6 +211,7 @@ struct SetGuard {
 }  // namespace
 
 struct pn_sharded {
+    int profile = 0;  // PN_OPT_PROFILE (also forwarded to the shards)
     uint64_t n_total = 0;
     size_t dim = 0;
     uint64_t per = 0;  // rows per shard = ceil(n_total / n_shards)
@@ -238,6 +246,9 @@ static void destroy_dev(Dev &d) {
                    &d.rad_a, &d.rad_b};
     for (Buf *b : bufs) b->release();
     d.free_retired();
+    for (auto &tr : d.ev_prof)
+        for (hipEvent_t e : tr)
+            if (e) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {d.ev_local[0], d.ev_local[1], d.ev_merged[0], d.ev_merged[1], d.ev_done, d.ev_use};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
@@ -424,14 +435,40 @@ extern "C" int pn_sharded_set_option(pn_sharded *sh, int option, int64_t value) 
         sh->exchange_always = value != 0;
         return PN_OK;
     }
+    if (option == PN_OPT_PROFILE) sh->profile = value != 0 ? 1 : 0;  // (and on to the shards below)
     for (Part &p : sh->parts)
         if (p.ix) SPN(pn_index_set_option(p.ix, option, value));
     return PN_OK;
 }
 
+static void prof_resolve(Dev &d, int slot, bool wait) {
+    if (!d.prof_pending[slot]) return;
+    if (wait) (void)hipEventSynchronize(d.ev_prof[slot][2]);
+    float a = 0.0f, b = 0.0f;
+    if (hipEventElapsedTime(&a, d.ev_prof[slot][0], d.ev_prof[slot][1]) == hipSuccess &&
+        hipEventElapsedTime(&b, d.ev_prof[slot][1], d.ev_prof[slot][2]) == hipSuccess) {
+        d.shard_ms += a;
+        d.exchange_ms += b;
+        d.prof_pending[slot] = false;
+    } else if (wait) {
+        d.prof_pending[slot] = false;
+    }
+    (void)hipGetLastError();
+}
+
 extern "C" int pn_sharded_get_stats(const pn_sharded *sh, pn_stats *out, int reset) {
     if (!sh || !out) return set_error(PN_ERR_INVALID, "NULL argument");
     pn_stats acc{};
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        for (Dev &d : sh->devs) {
+            SetGuard g(d.device);
+            for (int i = 0; i < Dev::kProf; ++i) prof_resolve(d, i, true);
+            acc.shard_ms += d.shard_ms;
+            acc.exchange_ms += d.exchange_ms;
+            if (reset) d.shard_ms = d.exchange_ms = 0.0;
+        }
+    }
     for (const Part &p : sh->parts) {
         if (!p.ix) continue;
         pn_stats s{};
@@ -531,6 +568,15 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
     const bool overlapped = nq > chunk;  // two chunks in flight: exchange + merge on the second stream
     SPN(acquire_dev(d, s));
     DevUse in_use{d, s};  // records the end-of-use event on every return path
+    // PN_OPT_PROFILE, batches of one chunk: local half and exchange half between three events on the caller's stream
+    int pslot = -1;
+    if (sh->profile && !overlapped) {
+        pslot = (int)(d.prof_next++ % Dev::kProf);
+        prof_resolve(d, pslot, true);  // (a slot comes round again after kProf calls: long finished)
+        for (hipEvent_t &e : d.ev_prof[pslot])
+            if (!e) SHIP(hipEventCreate(&e));
+        SHIP(hipEventRecord(d.ev_prof[pslot][0], s));
+    }
     int set = 0;
     size_t n_chunks = 0;
     for (size_t q0 = 0; q0 < nq; q0 += chunk, set ^= 1, ++n_chunks) {
@@ -546,8 +592,13 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
             SHIP(hipStreamWaitEvent(d.comm_stream, d.ev_local[set], 0));
             xs = d.comm_stream;
         }
+        if (pslot >= 0) SHIP(hipEventRecord(d.ev_prof[pslot][1], s));
         SNCCL(rccl().AllGather(d.pack[set].p, d.gathered[set].p, words, ncclUint64, d.comm, xs));
         SPN(enqueue_merge(sh, d, nqc, kd, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
+        if (pslot >= 0) {
+            SHIP(hipEventRecord(d.ev_prof[pslot][2], s));
+            d.prof_pending[pslot] = true;
+        }
         if (overlapped) SHIP(hipEventRecord(d.ev_merged[set], xs));
     }
     if (overlapped) {  // results are ready in the order of the caller's stream

@@ -330,7 +330,9 @@ def test_shared_thresholds_only_change_the_candidate_count(pn, oracle_mod):
     answers must be bit-identical with the option off, on, and with a rank so small (r = 2) that the thresholds drop
     below the true neighbours and nearly every query has to be answered by the next tier."""
     from petal_neighbors_amd import _lib
-    n, dim, nq, k = 300_000, 128, 3000, 10  # 12 query tiles x 32 segments = 384 main workgroups, refreshers behind them
+    # 12 query tiles x 32 segments = 384 main workgroups of 586 row tiles each (shared thresholds need runs of >= 512
+    # tiles: a refresher pass takes ~0.25 ms), refreshers behind them
+    n, dim, nq, k = 1_200_000, 128, 3000, 10
     pts, qs = uniform((n, dim), 3101), uniform((nq, dim), 3102)
     want_i, want_d = oracle_mod.brute_knn(pts, qs[:200], k)
     tree = pn.BallTree.euclidean(pts)
