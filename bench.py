@@ -225,6 +225,85 @@ def verify_radius(out, q_host, n, dim, nq, radius, tree):
     return res
 
 
+def bench_f64(args):
+    """--dtype f64: the same k-NN step on an f64 index (the reference is generic over A and its own harness is f64,
+    benches/ball_tree.rs:9-13): the bf16 MFMA filter over the f64 corpus' tile images, then the f64 re-rank, proof and
+    second tier.  One GPU; corpus built through the host API (f64 rows have no device-side generator); queries and
+    results resident in HBM, one pn_query_device_f64 call per step."""
+    import oracle
+    import petal_neighbors_amd as pn
+    from petal_neighbors_amd import _lib
+    torch.cuda.set_device(0)
+    n, dim, nq, k = CONFIGS[args.config]
+    # f64 coordinates with more than 24 significant bits: two f32 draws, the second scaled by 2^-24
+    pts = (oracle.fill_uniform(n * dim, SEED_P).astype(np.float64) +
+           oracle.fill_uniform(n * dim, SEED_P + 7).astype(np.float64) * 2.0 ** -24).reshape(n, dim)
+    qs = (oracle.fill_uniform(nq * dim, SEED_Q).astype(np.float64) +
+          oracle.fill_uniform(nq * dim, SEED_Q + 7).astype(np.float64) * 2.0 ** -24).reshape(nq, dim)
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine(args.engine)
+    tree.set_option(_lib.PN_OPT_PROFILE, 1)
+    qd = torch.from_numpy(qs).to("cuda:0")
+    out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device="cuda:0")
+    out_dst = torch.empty((nq, min(k, n)), dtype=torch.float64, device="cuda:0")
+    for _ in range(args.warmup):
+        tree.query_device(qd, k, out_idx, out_dst)
+    torch.cuda.synchronize()
+    tree.stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tree.query_device(qd, k, out_idx, out_dst)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = tree.stats()
+    verified = None
+    if not args.no_verify:
+        verified = {"ok": True, "checks": []}
+
+        def chk(name, ok):
+            verified["checks"].append(name if ok else name + ": FAILED")
+            verified["ok"] = verified["ok"] and bool(ok)
+        gi, gd = out_idx.cpu().numpy(), out_dst.cpu().numpy()
+        chk("ascending", bool((gd[:, 1:] >= gd[:, :-1]).all()) if gd.shape[1] > 1 else True)
+        sel = np.linspace(0, nq - 1, 32).astype(np.int64)
+        wi, wd = oracle.brute_knn(pts, qs[sel], k)
+        chk("oracle f64 brute force on 32 sampled queries",
+            np.array_equal(gi[sel].astype(np.uint64), wi) and gd[sel].tobytes() == wd.tobytes())
+        ne = min(nq, 1024)
+        esel = torch.linspace(0, nq - 1, ne, device="cuda:0").long()
+        tree.set_engine("exact")
+        ei, ed = tree.query_device(qd[esel].contiguous(), k)
+        torch.cuda.synchronize()
+        chk(f"exact f64 engine on {ne} queries", torch.equal(ei, out_idx[esel]) and
+            torch.equal(ed.view(torch.int64), out_dst[esel].view(torch.int64)))
+    launches = max(int(st["hot_launches"]), 1)
+    hot_ms = st["hot_ms"] / launches
+    flops_per_launch = 2.0 * n * dim * nq * args.steps / launches
+    achieved = flops_per_launch / (hot_ms * 1e-3) / 1e12 if hot_ms > 0 else 0.0
+    bf = args.engine in ("auto", "bf16") and tree.bf16_eligible
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    ms_per_step = elapsed / args.steps * 1e3
+    line = {
+        "metric": f"exact k-NN queries/sec ({n} x {dim} fp64, k={k})", "value": round(nq * args.steps / elapsed, 1),
+        "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config} f64: {n} points x {dim} dims f64, {nq} queries, k={k}, uniform[0,1) with 48 "
+                               f"random bits", "n_points": n, "dim": dim, "n_queries": nq, "k": k,
+                   "engine": "bf16 filter + f64 re-rank" if bf else "exact f64 scan"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": ("bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel") if bf else "exact_knn_kernel",
+                     "mfma_dtype": "bf16" if bf else "none (f64 vector unit)", "kernel_ms": round(hot_ms, 4),
+                     "flops_per_launch": flops_per_launch, "launches_per_step": round(launches / max(args.steps, 1), 2),
+                     "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4)},
+        "verified": bool(verified["ok"]) if verified else None, "verify": verified,
+        "fallback_queries": int(st["fallback_queries"]),
+        "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
+        "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),
+    }
+    print(json.dumps(line), flush=True)
+
+
 def plumbing(args):
     """--config c1: the reference's own harness shapes and call pattern (benches/ball_tree.rs:8-62) -- f64, one point
     per call through the host API, queries = corpus rows -- plus BASELINE.json's configs[0] shape (1000 x 3, k = 2) and
@@ -300,6 +379,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="PN_OPT_FILTER_SLOTS (k' of the MFMA filter); 0 = auto")
     ap.add_argument("--structure", type=int, default=0, help="PN_OPT_MFMA_STRUCTURE; 0 = auto")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity leg (outside the timed region)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
+                    help="f64: the k-NN step on an f64 index (bf16 filter + f64 re-rank), one GPU")
     ap.add_argument("--mode", default="knn", choices=["knn", "radius"],
                     help="radius: BallTree::query_radius over the batch (host queries in, host CSR out), one GPU")
     ap.add_argument("--radius", default="0.5",
@@ -326,6 +407,10 @@ def main():
 
     if args.config == "c1":
         return plumbing(args)
+    if args.dtype == "f64":
+        if args.gpus != 1 or args.mode != "knn":
+            sys.exit("bench.py: --dtype f64 is the one-GPU k-NN step")
+        return bench_f64(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:

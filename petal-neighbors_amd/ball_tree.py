@@ -257,12 +257,11 @@ class BallTree:
 
     # --------------------------------------------------------- device-resident
     def query_device(self, queries, k: int, out_idx=None, out_dist=None, stream=None):
-        """k-NN with queries and results in HBM (torch CUDA tensors, float32 indices as int64)."""
+        """k-NN with queries and results in HBM (torch CUDA tensors of the tree's element type; indices as int64)."""
         import torch
-        if self._sfx != "f32":
-            raise NotImplementedError("query_device is float32-only")
-        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_cuda:
-            raise ValueError("queries must be a 2-D float32 CUDA tensor")
+        tdt = torch.float32 if self._sfx == "f32" else torch.float64
+        if queries.dtype != tdt or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError(f"queries must be a 2-D {tdt} CUDA tensor")
         if queries.shape[1] > 1 and queries.stride(1) != 1:
             queries = queries.contiguous()
         nq, qc = queries.shape
@@ -270,10 +269,10 @@ class BallTree:
         if out_idx is None:
             out_idx = torch.empty((nq, kout), dtype=torch.int64, device=queries.device)
         if out_dist is None:
-            out_dist = torch.empty((nq, kout), dtype=torch.float32, device=queries.device)
+            out_dist = torch.empty((nq, kout), dtype=tdt, device=queries.device)
         if nq and kout:
             st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
-            check(_lib.lib().pn_query_device_f32(self._h, queries.data_ptr(), nq, qc,
+            check(getattr(_lib.lib(), f"pn_query_device_{self._sfx}")(self._h, queries.data_ptr(), nq, qc,
                                                  queries.stride(0) if nq > 1 else max(qc, 1), int(k),
                                                  out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
         return out_idx, out_dist

@@ -187,7 +187,10 @@ __device__ __forceinline__ size_t bf_wide_at(size_t r, int k, int dim) {  // bf1
 
 // One thread per (padded) corpus row: bf16 row + the five extra columns, written into the tile image.
 // narrow (D <= 128): img = [n_tiles][64][CP][8] bf16, CP = 2*KS + 1 chunks per row (last chunk is padding).
-__global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
+// T: the index's element type.  An f64 corpus gets the SAME bf16 images (the bound is a statement about real vectors;
+// every constant is computed in f64 from the f64 coordinates), so f64 indexes are served by this tier too.
+template <typename T>
+__global__ void bf16_pack_corpus_kernel(const T *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
                                         size_t ld, int KS, uint16_t *__restrict__ img, size_t n_rows_img,
                                         uint32_t *__restrict__ bad, int wide, int ci) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,11 +219,11 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
     }
     double pn = 0.0, en = 0.0, hn = 0.0;
     bool finite = true;
-    const float *src = P + r * ld;
+    const T *src = P + r * ld;
     for (int k = 0; k < dim; ++k) {
-        const float x = src[k];
-        finite = finite && (fabsf(x) < 1.0e30f);  // also false for NaN
-        const double c = (double)x - (double)mu[k];  // centred coordinate (header: translation)
+        const double x = (double)src[k];
+        finite = finite && (fabs(x) < 1.0e30);  // also false for NaN
+        const double c = x - (double)mu[k];  // centred coordinate (header: translation)
         const float cf = (float)c;
         const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);  // 2^-60
         const float xh = bf_f(hb);
@@ -257,18 +260,19 @@ __global__ void bf16_pack_corpus_kernel(const float *__restrict__ P, const float
 // The per-row constants Bp, Dp of the bound over the whole corpus (f64, before their bf16 rounding): out[0] = max Bp,
 // out[1] = max Dp (bit patterns of non-negative doubles order like integers), out[2] = sum Bp, out[3] = sum Dp.
 // Decides whether the CI layout serves this corpus and provides the maxima E(q) is built from.
-__global__ void bf16_row_stats_kernel(const float *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
+template <typename T>
+__global__ void bf16_row_stats_kernel(const T *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
                                       size_t ld, double *__restrict__ out) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double bp = 0.0, dp = 0.0;
     if (r < n) {
         double pn = 0.0, en = 0.0, hn = 0.0;
         bool finite = true;
-        const float *src = P + r * ld;
+        const T *src = P + r * ld;
         for (int k = 0; k < dim; ++k) {
-            const float x = src[k];
-            finite = finite && (fabsf(x) < 1.0e30f);
-            const double c = (double)x - (double)mu[k];
+            const double x = (double)src[k];
+            finite = finite && (fabs(x) < 1.0e30);
+            const double c = x - (double)mu[k];
             const float cf = (float)c;
             const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const double xh = (double)bf_f(hb);
@@ -298,7 +302,8 @@ __global__ void bf16_row_stats_kernel(const float *__restrict__ P, const float *
 
 // One thread per (padded) query: bf16 B row [K] (chunk c at 8c), |q|^2 rounded down (f64), flag.
 // ci: no extra columns; qn[q] = |q|^2 (down) - E(q) (up), E(q) = Aq bmax + Cq dmax (header of bf16_ci_dim)
-__global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
+template <typename T>
+__global__ void bf16_pack_queries_kernel(const T *__restrict__ Q, const float *__restrict__ mu, size_t nq,
                                          size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
                                          double *__restrict__ qn, uint32_t *__restrict__ qbad, int wide, int ci,
                                          double bmax, double dmax) {
@@ -315,11 +320,11 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
     double s = 0.0, en = 0.0, hn = 0.0;
     bool finite = true;
     if (q < nq) {
-        const float *src = Q + q * ld;
+        const T *src = Q + q * ld;
         for (int k = 0; k < dim; ++k) {
-            const float x = src[k];
-            finite = finite && (fabsf(x) < 1.0e30f);
-            const double c = (double)x - (double)mu[k];
+            const double x = (double)src[k];
+            finite = finite && (fabs(x) < 1.0e30);
+            const double c = x - (double)mu[k];
             const float cf = (float)c;
             const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const float xh = bf_f(hb);
@@ -359,10 +364,11 @@ __global__ void bf16_pack_queries_kernel(const float *__restrict__ Q, const floa
 // Qp (nullable): the call's FIRST kernel -- Q then is the caller's query array itself (row stride ld, at least dim
 // columns), and this kernel also writes the zero-padded f32 copy Qp[nq_pad][ldq] that the re-rank and the next tier read
 // (pack_rows_kernel's job) and zeroes the call's 16 counter words `misc` (a memset's job): one launch instead of three.
-__global__ void bf16_pack_queries8_kernel(const float *__restrict__ Q, const float *__restrict__ mu, size_t nq,
+template <typename T>
+__global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *__restrict__ mu, size_t nq,
                                           size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
                                           double *__restrict__ qn, uint32_t *__restrict__ qbad, int ci, double bmax,
-                                          double dmax, float *__restrict__ Qp, size_t ldq,
+                                          double dmax, T *__restrict__ Qp, size_t ldq,
                                           uint32_t *__restrict__ misc) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t q = t >> 3;
@@ -374,25 +380,28 @@ __global__ void bf16_pack_queries8_kernel(const float *__restrict__ Q, const flo
     uint16_t v[18];  // CH <= 18 (KS <= 9)
     double s = 0.0, en = 0.0, hn = 0.0;
     bool finite = true;
-    const float *src = Q + q * ld;
+    const T *src = Q + q * ld;
     if (Qp) {  // columns of the padded copy that no lane's eighth of the K columns covers (ldq > K, e.g. D = 100)
-        for (int k = K + sub; k < (int)ldq; k += 8) Qp[q * ldq + k] = 0.0f;
+        for (int k = K + sub; k < (int)ldq; k += 8) Qp[q * ldq + k] = (T)0;
     }
     // this lane's CH coordinates: 16-byte loads when the source rows allow it (the usual case: a contiguous array
     // with a multiple of four columns), and 16- or 8-byte stores into the padded copy (its rows are 32-byte aligned)
-    float xf[18];
+    T xf[18];
     const bool in_rows = q < nq;
-    const bool vec = (CH % 4) == 0 && ((reinterpret_cast<uintptr_t>(Q) | (ld * sizeof(float))) & 15u) == 0 &&
+    constexpr int VE = 16 / (int)sizeof(T);  // elements per 16-byte access
+    const bool vec = (CH % 4) == 0 && ((reinterpret_cast<uintptr_t>(Q) | (ld * sizeof(T))) & 15u) == 0 &&
                      c0 + CH <= dim;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) xf[i] = 0.0f;
+    for (int i = 0; i < 18; ++i) xf[i] = (T)0;
     if (in_rows) {
         if (vec) {
 #pragma unroll
-            for (int i = 0; i < 18; i += 4)
-                if (i + 4 <= CH) {
-                    const float4 t4 = *reinterpret_cast<const float4 *>(src + c0 + i);
-                    xf[i] = t4.x; xf[i + 1] = t4.y; xf[i + 2] = t4.z; xf[i + 3] = t4.w;
+            for (int i = 0; i < 18; i += VE)
+                if (i + VE <= CH) {
+                    typedef T tv_ __attribute__((ext_vector_type(VE)));
+                    const tv_ t4 = *reinterpret_cast<const tv_ *>(src + c0 + i);
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) xf[i + j] = t4[j];
                 }
         } else {
 #pragma unroll
@@ -401,20 +410,25 @@ __global__ void bf16_pack_queries8_kernel(const float *__restrict__ Q, const flo
         }
     }
     if (Qp) {
-        float *qd = Qp + q * ldq + c0;
+        T *qd = Qp + q * ldq + c0;
 #pragma unroll
         for (int i = 0; i < 18; i += 2)
-            if (i + 2 <= CH && c0 + i + 2 <= (int)ldq)  // (CH and ldq are even: pairs never straddle the row end)
-                *reinterpret_cast<float2 *>(qd + i) = make_float2(xf[i], xf[i + 1]);
+            if (i + 2 <= CH && c0 + i + 2 <= (int)ldq) {  // (CH and ldq are even: pairs never straddle the row end)
+                typedef T tp_ __attribute__((ext_vector_type(2)));
+                tp_ pr;
+                pr[0] = xf[i];
+                pr[1] = xf[i + 1];
+                *reinterpret_cast<tp_ *>(qd + i) = pr;
+            }
     }
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         v[i] = 0;
         const int k = c0 + i;
         if (i < CH && k < dim && q < nq) {
-            const float x = xf[i];
-            finite = finite && (fabsf(x) < 1.0e30f);
-            const double c = (double)x - (double)mu[k];
+            const double x = (double)xf[i];
+            finite = finite && (fabs(x) < 1.0e30);
+            const double c = x - (double)mu[k];
             const float cf = (float)c;
             const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const float xh = bf_f(hb);
@@ -2236,14 +2250,15 @@ int bf16_cell_max(int kp, int cap) {
 
 // per-dimension sums of the corpus in f64 (any translation vector is valid; the mean minimises the norms);
 // sums[dim] receives the sum of all squares
-__global__ void bf16_column_sums_kernel(const float *__restrict__ P, size_t n, int dim, size_t ld, double *__restrict__ sums) {
+template <typename T>
+__global__ void bf16_column_sums_kernel(const T *__restrict__ P, size_t n, int dim, size_t ld, double *__restrict__ sums) {
     const size_t r0 = (size_t)blockIdx.x * 1024;
     const size_t r1 = r0 + 1024 < n ? r0 + 1024 : n;
     for (int k = threadIdx.x; k < dim; k += blockDim.x) {
         double a = 0.0, b = 0.0;
         for (size_t r = r0; r < r1; ++r) {
-            const float x = P[r * ld + k];
-            const double v = (fabsf(x) < 1.0e30f) ? (double)x : 0.0;
+            const double x = (double)P[r * ld + k];
+            const double v = (fabs(x) < 1.0e30) ? x : 0.0;
             a += v;
             b += v * v;
         }
@@ -2251,26 +2266,35 @@ __global__ void bf16_column_sums_kernel(const float *__restrict__ P, size_t n, i
         atomicAdd(&sums[dim], b);
     }
 }
-hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_column_sums_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(128), 0, s, P, n, dim, ld, sums);
+template <typename T>
+hipError_t launch_bf16_column_sums(const T *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_column_sums_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(128), 0, s, P, n, dim, ld, sums);
     return hipGetLastError();
 }
+template hipError_t launch_bf16_column_sums<float>(const float *, size_t, int, size_t, double *, hipStream_t);
+template hipError_t launch_bf16_column_sums<double>(const double *, size_t, int, size_t, double *, hipStream_t);
 
-hipError_t launch_bf16_row_stats(const float *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
+template <typename T>
+hipError_t launch_bf16_row_stats(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
                                  hipStream_t s) {
-    hipLaunchKernelGGL(bf16_row_stats_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld, out4);
+    hipLaunchKernelGGL(bf16_row_stats_kernel<T>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld, out4);
     return hipGetLastError();
 }
+template hipError_t launch_bf16_row_stats<float>(const float *, const float *, size_t, int, size_t, double *, hipStream_t);
+template hipError_t launch_bf16_row_stats<double>(const double *, const float *, size_t, int, size_t, double *, hipStream_t);
 
-hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
+template <typename T>
+hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int dim, size_t ld, void *img,
                                    uint32_t *bad, bool ci, hipStream_t s) {
     const bool wide = bf16_is_wide(dim);
     if (wide && ci) return hipErrorInvalidValue;
     const size_t rows = wide ? (n + kWR - 1) / kWR * kWR : (n + kBP - 1) / kBP * kBP;
-    hipLaunchKernelGGL(bf16_pack_corpus_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
+    hipLaunchKernelGGL(bf16_pack_corpus_kernel<T>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
                        bf16_ks_for(dim, ci), static_cast<uint16_t *>(img), rows, bad, wide ? 1 : 0, ci ? 1 : 0);
     return hipGetLastError();
 }
+template hipError_t launch_bf16_pack_corpus<float>(const float *, const float *, size_t, int, size_t, void *, uint32_t *, bool, hipStream_t);
+template hipError_t launch_bf16_pack_corpus<double>(const double *, const float *, size_t, int, size_t, void *, uint32_t *, bool, hipStream_t);
 
 bool bf16_pack_fused_supported(int dim) {
 #ifdef PN_DIAG_BF_PACKQ1
@@ -2279,23 +2303,28 @@ bool bf16_pack_fused_supported(int dim) {
     return !bf16_is_wide(dim);
 #endif
 }
-hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
+template <typename T>
+hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s, float *Qp, size_t ldq, uint32_t *misc) {
+                                    hipStream_t s, T *Qp, size_t ldq, uint32_t *misc) {
     if ((Qp || misc) && !bf16_pack_fused_supported(dim)) return hipErrorInvalidValue;
 #ifndef PN_DIAG_BF_PACKQ1
     if (!bf16_is_wide(dim)) {  // nq_pad is a multiple of 256: whole blocks
-        hipLaunchKernelGGL(bf16_pack_queries8_kernel, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
+        hipLaunchKernelGGL(bf16_pack_queries8_kernel<T>, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
                            nq_pad, dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, ci ? 1 : 0,
                            bmax, dmax, Qp, ldq, misc);
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(bf16_pack_queries_kernel, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
+    hipLaunchKernelGGL(bf16_pack_queries_kernel<T>, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
                        dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, bf16_is_wide(dim) ? 1 : 0,
                        ci ? 1 : 0, bmax, dmax);
     return hipGetLastError();
 }
+template hipError_t launch_bf16_pack_queries<float>(const float *, const float *, size_t, size_t, int, size_t, void *, double *,
+                                                    uint32_t *, bool, double, double, hipStream_t, float *, size_t, uint32_t *);
+template hipError_t launch_bf16_pack_queries<double>(const double *, const float *, size_t, size_t, int, size_t, void *, double *,
+                                                     uint32_t *, bool, double, double, hipStream_t, double *, size_t, uint32_t *);
 
 // The branch-free capture path (CAPT, see the kernel) is measured, parity-tested and NOT used by default: it wins where
 // survivors are frequent and the kernel is launched with thresholds (1M x 128, k = 100: 4.50 -> 4.20 ms) but needs ~25

@@ -312,9 +312,9 @@ hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, c
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                 const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const double *pnorm,
-                                const double *qnorm, hipStream_t s) {
+                                const double *qnorm, hipStream_t s, const uint32_t *qsel) {
     return launch_exact_knn<double>(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lo_key, lo_idx, nq_dev, nq_off, pnorm,
-                                    qnorm, s);
+                                    qnorm, s, qsel);
 }
 
 // ---------------------------------------------------------------------------

@@ -281,18 +281,21 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
         HIPCHK(hipStreamSynchronize(s));
         return PN_OK;
     }
-    if (sizeof(T) == 4) {
-        HIPCHK(hipMalloc((void **)&ix->d_norm, ix->n_pad * sizeof(float)));
-        uint32_t *d_flag = nullptr;
-        HIPCHK(hipMalloc((void **)&d_flag, sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s));
-        HIPCHK(launch_row_norms_f32((const float *)ix->d_pts, ix->n_pad, ix->n, (int)ix->dim, ix->ld,
-                                    mfma_alpha(ix->dim), ix->d_norm, d_flag, s));
-        uint32_t h_flag = 0;
-        HIPCHK(hipMemcpyAsync(&h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        (void)hipFree(d_flag);
-        ix->mfma_ok = (h_flag == 0) && mfma_supported((int)ix->dim, ix->ld) && ix->n < 0xFFFFFFF0ull;
+    {
+        if constexpr (sizeof(T) == 4) {
+            HIPCHK(hipMalloc((void **)&ix->d_norm, ix->n_pad * sizeof(float)));
+            uint32_t *d_flag = nullptr;
+            HIPCHK(hipMalloc((void **)&d_flag, sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s));
+            HIPCHK(launch_row_norms_f32((const float *)ix->d_pts, ix->n_pad, ix->n, (int)ix->dim, ix->ld,
+                                        mfma_alpha(ix->dim), ix->d_norm, d_flag, s));
+            uint32_t h_flag = 0;
+            HIPCHK(hipMemcpyAsync(&h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            (void)hipFree(d_flag);
+            ix->mfma_ok = (h_flag == 0) && mfma_supported((int)ix->dim, ix->ld) && ix->n < 0xFFFFFFF0ull;
+        }
+        // bf16 tier: for f32 AND f64 indexes (the images are built from the index's own coordinates in f64 arithmetic)
         ix->bf16_ok = false;
         if (bf16_supported((int)ix->dim) && ix->n < 0xFFFFFFF0ull && ix->n >= 64) {
             uint32_t *d_bad = nullptr;
@@ -302,7 +305,7 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
                 double *d_sums = nullptr;
                 HIPCHK(hipMalloc((void **)&d_sums, (ix->dim + 1) * sizeof(double)));
                 HIPCHK(hipMemsetAsync(d_sums, 0, (ix->dim + 1) * sizeof(double), s));
-                HIPCHK(launch_bf16_column_sums((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, d_sums, s));
+                HIPCHK(launch_bf16_column_sums<T>((const T *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, d_sums, s));
                 std::vector<double> h_sums(ix->dim + 1);
                 HIPCHK(hipMemcpyAsync(h_sums.data(), d_sums, (ix->dim + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
@@ -337,7 +340,7 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
                 double *d_st = nullptr, h_st[4] = {0, 0, 0, 0};
                 HIPCHK(hipMalloc((void **)&d_st, sizeof h_st));
                 HIPCHK(hipMemsetAsync(d_st, 0, sizeof h_st, s));
-                HIPCHK(launch_bf16_row_stats((const float *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, d_st, s));
+                HIPCHK(launch_bf16_row_stats<T>((const T *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, d_st, s));
                 HIPCHK(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 (void)hipFree(d_st);
@@ -349,8 +352,8 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
             }
 #endif
             HIPCHK(hipMalloc(&ix->d_img, bf16_image_bytes(ix->n, (int)ix->dim, ix->bf16_ci)));
-            HIPCHK(launch_bf16_pack_corpus((const float *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, ix->d_img,
-                                           d_bad, ix->bf16_ci, s));
+            HIPCHK(launch_bf16_pack_corpus<T>((const T *)ix->d_pts, ix->d_mu, ix->n, (int)ix->dim, ix->ld, ix->d_img,
+                                              d_bad, ix->bf16_ci, s));
             uint32_t h_bad = 0;
             HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -361,7 +364,6 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
                 ix->d_img = nullptr;
             }
         }
-    } else {
         HIPCHK(hipStreamSynchronize(s));
     }
     return PN_OK;
@@ -792,6 +794,13 @@ static ScanPlan plan_segments(size_t n, size_t q_tiles, int cap, int forced, siz
 // ---------------------------------------------------------------------------
 template <typename T> struct Ops;
 template <> struct Ops<float> {
+    static hipError_t rerank(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
+                             size_t ldq, int kout, uint64_t base, uint64_t *io, float *dd, size_t os, uint32_t *flags,
+                             uint32_t *nf, const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *st,
+                             hipStream_t s, int fe, int cm) {
+        return launch_select_rerank_f32(cb, P, n, dim, ldp, Q, nq, ldq, kout, base, io, dd, os, flags, nf, qn, qbad, sel, st,
+                                        s, fe, cm);
+    }
     static hipError_t pack(const float *s, size_t n, size_t c, size_t rs, float *d, size_t np, size_t ld, hipStream_t st) {
         return launch_pack_rows_f32(s, n, c, rs, d, np, ld, st);
     }
@@ -810,21 +819,28 @@ template <> struct Ops<float> {
     }
 };
 template <> struct Ops<double> {
+    static hipError_t rerank(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
+                             size_t ldq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os, uint32_t *flags,
+                             uint32_t *nf, const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *st,
+                             hipStream_t s, int fe, int cm) {
+        return launch_select_rerank_f64(cb, P, n, dim, ldp, Q, nq, ldq, kout, base, io, dd, os, flags, nf, qn, qbad, sel, st,
+                                        s, fe, cm);
+    }
     static hipError_t pack(const double *s, size_t n, size_t c, size_t rs, double *d, size_t np, size_t ld, hipStream_t st) {
         return launch_pack_rows_f64(s, n, c, rs, d, np, ld, st);
     }
     static hipError_t knn(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq, size_t ldq, int kp,
                           size_t seg_len, const CandBuf &cb, const void *lk, const uint32_t *li, const uint32_t *nd,
-                          uint32_t no, const double *pn, const double *qn, hipStream_t s, const uint32_t * = nullptr) {
-        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s);
+                          uint32_t no, const double *pn, const double *qn, hipStream_t s, const uint32_t *qsel = nullptr) {
+        return launch_exact_knn_f64(P, n, dim, ldp, Q, nq, ldq, kp, seg_len, cb, lk, li, nd, no, pn, qn, s, qsel);
     }
     static hipError_t cnorms(const double *X, size_t n, int dim, size_t ld, double *o, hipStream_t s) {
         return launch_cosine_norms_f64(X, n, dim, ld, o, s);
     }
     static hipError_t select(const CandBuf &cb, int nq, int kout, uint64_t base, uint64_t *io, double *dd, size_t os,
                              size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s,
-                             const uint32_t * = nullptr) {
-        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s);
+                             const uint32_t *osel = nullptr) {
+        return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s, osel);
     }
 };
 
@@ -890,12 +906,14 @@ static int run_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, 
 // is left there for a LATER call to look at; returns *count_published = true when a kernel here does that.
 constexpr size_t kSecondTierRows = 16384;
 constexpr size_t kSecondTierFew = 256;  // the first flagged queries of a chunk take the many-segment path below
-static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kout,
-                             const uint32_t *d_sel, const uint32_t *d_nsel, uint64_t *d_idx, float *d_dist,
+template <typename T>
+static int second_tier_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t kout,
+                             const uint32_t *d_sel, const uint32_t *d_nsel, uint64_t *d_idx, T *d_dist,
                              size_t out_stride, hipStream_t s, uint32_t *h_count, bool *count_published) {
     const size_t F = nq < kSecondTierRows ? nq : kSecondTierRows, F_pad = round_up(F, (size_t)256);
     *count_published = false;
     size_t first = 0;
+    if constexpr (sizeof(T) == 4) {  // (f64 indexes: every flagged query takes the rounds below)
     // Few flagged queries are the normal case, and they share ONE 64-query tile: with the usual <= 32 segments that is
     // <= 32 workgroups for the whole corpus (10M rows: 0.4 s for a single flagged query).  So the first 256 flagged
     // queries of a chunk are scanned with up to 512 row segments -- every CU busy -- and selected in two levels:
@@ -931,10 +949,11 @@ static int second_tier_exact(const pn_index *ix, Workspace &ws, const float *Qp,
         *count_published = h_count != nullptr;
         first = Ff;
     }
+    }
     for (size_t off = first; off < nq; off += F) {
         const size_t fr = nq - off < F ? nq - off : F;
-        PNCHK(run_exact<float>(ix, ws, Qp, fr, F_pad, (int)ix->dim, kout, d_idx, d_dist, out_stride, s, true, d_nsel,
-                               (uint32_t)off, nullptr, nullptr, d_sel));
+        PNCHK(run_exact<T>(ix, ws, Qp, fr, F_pad, (int)ix->dim, kout, d_idx, d_dist, out_stride, s, true, d_nsel,
+                           (uint32_t)off, nullptr, nullptr, d_sel));
     }
     return PN_OK;
 }
@@ -1263,9 +1282,10 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
 // bf16 filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for the unproven queries
 // d_q_raw (nullable; narrow rows): the caller's queries, row stride q_stride -- Qp has NOT been filled and the call's
 // counters have not been zeroed yet: the query pack kernel does both on the way (one launch at the head of the call)
-static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, const float *Qp, size_t nq, size_t nq_pad,
-                    size_t kout, uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s, CallRec *rec,
-                    const float *d_q_raw = nullptr, size_t q_stride = 0) {
+template <typename T>
+static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, const T *Qp, size_t nq, size_t nq_pad,
+                    size_t kout, uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s, CallRec *rec,
+                    const T *d_q_raw = nullptr, size_t q_stride = 0) {
     if (!plan.ok) return fail(PN_ERR_UNSUPPORTED, "bf16 tier cannot serve k = %zu", kout);
     const int n_wg = plan.n_wg, cap = plan.cap, nseg = plan.nseg;
     const size_t kp = (size_t)plan.kp;
@@ -1282,7 +1302,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     if (d_q_raw)
         HIPCHK(launch_bf16_pack_queries(d_q_raw, ix->d_mu, nq, nq_pad, (int)ix->dim, q_stride, ws.w_bq.p,
                                         (double *)ws.w_qn.p, (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax,
-                                        ix->bf16_dmax, s, const_cast<float *>(Qp), ix->ld, d_misc));
+                                        ix->bf16_dmax, s, const_cast<T *>(Qp), ix->ld, d_misc));
     else
         HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
                                         (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
@@ -1339,10 +1359,10 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
                                   plan.scout_max, nullptr, false, nullptr, ix->bf16_ci, s));
     }
     if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
-    HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
-                                    (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,
-                                    d_misc, (const double *)ws.w_qn.p, (const uint32_t *)ws.w_qbad.p,
-                                    (uint32_t *)ws.w_gsel.p, ix->d_stats, s, plan.first_eval, bf16_cell_max((int)kp, cap)));
+    HIPCHK(Ops<T>::rerank(cb, (const T *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld, (int)kout,
+                          ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p, d_misc,
+                          (const double *)ws.w_qn.p, (const uint32_t *)ws.w_qbad.p, (uint32_t *)ws.w_gsel.p, ix->d_stats, s,
+                          plan.first_eval, bf16_cell_max((int)kp, cap)));
     return PN_OK;
 }
 
@@ -1391,38 +1411,41 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
                 if (ix->ld > 128 && mfma_slots(ix, kout, nq_pad) > 30) use_mfma = false;  // wide rows: LDS-buffer kernel only
                 if (ix->engine == PN_ENGINE_AUTO && (ix->n < 4096 || ix->dim < 8)) use_mfma = false;
             }
-            if (ix->bf16_ok && dim_eff == ix->dim &&
-                (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
-                bplan = bf16_plan(ix, nq_pad, kout, level);
-                use_bf16 = bplan.ok;
-            }
+        }
+        // (f32 AND f64 indexes: the bf16 bound is a statement about real vectors -- an f64 index's candidates are then
+        // re-ranked in the reference's f64 fold and proven with u = 2^-53)
+        if (ix->bf16_ok && dim_eff == ix->dim &&
+            (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
+            bplan = bf16_plan(ix, nq_pad, kout, level);
+            use_bf16 = bplan.ok;
+            // the re-rank's LDS: (8 or 12) bytes per candidate slot + the query row
+            if (use_bf16 && (size_t)bplan.nseg * (size_t)bf16_cell_max(bplan.kp, bplan.cap) * (sizeof(T) + 8) +
+                                    (ix->dim + 8) * sizeof(T) > 64 * 1024)
+                use_bf16 = false;
         }
         // the head of the call: the zero-padded copy of the queries (+ the call's counters, zeroed) -- for narrow rows
         // on the bf16 tier both are by-products of the tier's own query pack kernel (run_bf16)
-        bool fused_head = false;
-        if constexpr (sizeof(T) == 4) fused_head = use_bf16 && !bplan.wide && bf16_pack_fused_supported((int)ix->dim);
+        const bool fused_head = use_bf16 && !bplan.wide && bf16_pack_fused_supported((int)ix->dim);
         if (!fused_head) HIPCHK(Ops<T>::pack(d_q + qs * q_stride, nqc, dim_eff, q_stride, Qp, nq_pad, ix->ld, s));
-        if constexpr (sizeof(T) == 4) {
-            if (use_bf16 || use_mfma) {
-                PNCHK(ws.w_misc.ensure(64));
-                if (!fused_head) HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
-                uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
-                if (use_bf16)
-                    PNCHK(run_bf16(ix, ws, bplan, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec,
-                                   fused_head ? (const float *)(d_q + qs * q_stride) : nullptr, q_stride));
-                else
-                    PNCHK(run_mfma(ix, ws, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
-                // the flagged count reaches pinned memory behind everything else (written by the second tier's merge
-                // kernel, else by a copy); a LATER call looks at it
-                uint32_t *h_dev = nullptr;
-                if (hipHostGetDevicePointer((void **)&h_dev, rec->h_nflag, 0) != hipSuccess) h_dev = nullptr;
-                bool published = false;
-                PNCHK(second_tier_exact(ix, ws, (const float *)Qp, nqc, kout, (const uint32_t *)ws.w_gsel.p, d_misc, oi,
-                                        (float *)od, out_stride, s, h_dev, &published));
-                if (!published) HIPCHK(hipMemcpyAsync(rec->h_nflag, d_misc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                rec->has_flag = true;
-                rec->bf16_tier = use_bf16;
-            }
+        if (use_bf16 || use_mfma) {
+            PNCHK(ws.w_misc.ensure(64));
+            if (!fused_head) HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
+            uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
+            if (use_bf16)
+                PNCHK(run_bf16<T>(ix, ws, bplan, (const T *)Qp, nqc, nq_pad, kout, oi, od, out_stride, s, rec,
+                                  fused_head ? (const T *)(d_q + qs * q_stride) : nullptr, q_stride));
+            else if constexpr (sizeof(T) == 4)
+                PNCHK(run_mfma(ix, ws, (const float *)Qp, nqc, nq_pad, kout, oi, (float *)od, out_stride, s, rec));
+            // the flagged count reaches pinned memory behind everything else (written by the second tier's merge
+            // kernel, else by a copy); a LATER call looks at it
+            uint32_t *h_dev = nullptr;
+            if (hipHostGetDevicePointer((void **)&h_dev, rec->h_nflag, 0) != hipSuccess) h_dev = nullptr;
+            bool published = false;
+            PNCHK(second_tier_exact<T>(ix, ws, (const T *)Qp, nqc, kout, (const uint32_t *)ws.w_gsel.p, d_misc, oi, od,
+                                       out_stride, s, h_dev, &published));
+            if (!published) HIPCHK(hipMemcpyAsync(rec->h_nflag, d_misc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            rec->has_flag = true;
+            rec->bf16_tier = use_bf16;
         }
         if (!use_bf16 && !use_mfma)
             PNCHK(run_exact<T>(ix, ws, Qp, nqc, nq_pad, (int)dim_eff, kout, oi, od, out_stride, s, false, nullptr, 0, rec, qnorm));

@@ -78,7 +78,7 @@ hipError_t launch_exact_knn_f32(const float *P, size_t n, int dim, size_t ldp, c
 hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                 size_t ldq, int kp, size_t seg_len, const CandBuf &cb, const void *lo_key,
                                 const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const double *pnorm,
-                                const double *qnorm, hipStream_t s);
+                                const double *qnorm, hipStream_t s, const uint32_t *qsel = nullptr);
 // radius: count pass (fill == nullptr) then fill pass.  counts/offsets are [query][seg].
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
@@ -111,7 +111,7 @@ hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                   hipStream_t s);
+                                   hipStream_t s, const uint32_t *osel = nullptr);
 hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, float *dist_out, size_t out_group_stride,
                                           const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
@@ -133,6 +133,12 @@ hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n,
                                     unsigned long long *stats, hipStream_t s, int first_eval = 0, int cell_max = 0);
 // first_eval: candidates (smallest bounds first) evaluated in the first round, >= kout (0: kout); cell_max: entries a
 // (segment, query) cell holds at most (0: cb.cap) -- sizes the kernel's LDS
+// f64 indexes behind the bf16 filter (qn required): distances in the reference's f64 fold, proof with u = 2^-53
+hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp,
+                                    const double *Q, int nq, size_t ldq, int kout, uint64_t index_base,
+                                    uint64_t *idx_out, double *dist_out, size_t out_stride, uint32_t *flags,
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
+                                    unsigned long long *stats, hipStream_t s, int first_eval = 0, int cell_max = 0);
 // osel (nullable): the merged result of query q goes to row osel[q] of the outputs (row stride out_stride, 0 = k_out);
 // host_count (nullable, mapped pinned memory): block 0 copies *nq_dev there (the count a LATER call looks at)
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
@@ -207,19 +213,23 @@ int bf16_cap_for(int kp);                          // slots per (segment, query)
 int bf16_query_tile();                             // queries per workgroup (256)
 // mu: translation vector [dim]; sums: [dim + 1] per-dimension f64 sums of the corpus + the sum of all squares
 // (zeroed by the caller)
-hipError_t launch_bf16_column_sums(const float *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
+template <typename T>  // T = float | double (explicitly instantiated): the index's element type
+hipError_t launch_bf16_column_sums(const T *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
 // out4 (zeroed by the caller): max Bp, max Dp, sum Bp, sum Dp over the rows
-hipError_t launch_bf16_row_stats(const float *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
+template <typename T>
+hipError_t launch_bf16_row_stats(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
                                  hipStream_t s);
-hipError_t launch_bf16_pack_corpus(const float *P, const float *mu, size_t n, int dim, size_t ld, void *img,
+template <typename T>
+hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int dim, size_t ld, void *img,
                                    uint32_t *bad, bool ci, hipStream_t s);
 // Qp / ldq / misc (nullable, narrow rows only: bf16_pack_fused_supported): Q is the CALLER's array (row stride ld); the
 // kernel also writes the zero-padded f32 copy Qp[nq_pad][ldq] and zeroes the 16 counter words at misc -- the three
 // launches at the head of a call in one
 bool bf16_pack_fused_supported(int dim);
-hipError_t launch_bf16_pack_queries(const float *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
+template <typename T>
+hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s, float *Qp = nullptr, size_t ldq = 0, uint32_t *misc = nullptr);
+                                    hipStream_t s, T *Qp = nullptr, size_t ldq = 0, uint32_t *misc = nullptr);
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);

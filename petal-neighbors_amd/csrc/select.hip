@@ -205,9 +205,9 @@ hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t
 hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    double *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
-                                   hipStream_t s) {
+                                   hipStream_t s, const uint32_t *osel) {
     return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, cb.cap, out_stride, out_off,
-                                       lo_key, lo_idx, nq_dev, nq_off, signed_keys, s);
+                                       lo_key, lo_idx, nq_dev, nq_off, signed_keys, s, 1, 0, osel);
 }
 
 // ---------------------------------------------------------------------------
@@ -312,6 +312,91 @@ __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t
     return T;
 }
 
+// ---- element-type generic pieces of the re-rank (T = float: the f32 functions above; T = double: an f64 index served
+// by the bf16 filter -- the bound is a statement about real vectors, only this kernel's arithmetic follows the type)
+template <typename T> __device__ __forceinline__ T exact_distance_seq(const T *__restrict__ q, const T *__restrict__ p, int dim);
+template <> __device__ __forceinline__ float exact_distance_seq<float>(const float *__restrict__ q, const float *__restrict__ p, int dim) {
+    return exact_distance_f32(q, p, dim);
+}
+template <> __device__ __forceinline__ double exact_distance_seq<double>(const double *__restrict__ q, const double *__restrict__ p, int dim) {
+#pragma clang fp contract(off)
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) {  // Euclidean::distance, src/distance.rs:26-35: sub, mul, add separately rounded, ascending k
+        const double d = q[k] - p[k];
+        s = s + d * d;
+    }
+    return sqrt(s);
+}
+template <typename T> __device__ __forceinline__ T exact_distance_prefetched(const T *qs, const T *__restrict__ p, int len);
+template <> __device__ __forceinline__ float exact_distance_prefetched<float>(const float *qs, const float *__restrict__ p, int len) {
+    return exact_distance_prefetched_f32(qs, p, len);
+}
+// f64: 16 independent 16-byte loads (32 coordinates) in flight per round; the query from LDS; len a multiple of 8
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ double exact_distance_prefetched<double>(const double *qs, const double *__restrict__ p, int len) {
+#pragma clang fp contract(off)
+    double s = 0.0;
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        f64x2_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (k0 + 2 * i < len) v[i] = *reinterpret_cast<const f64x2_t *>(p + k0 + 2 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (k0 + 2 * i < len) {
+                const f64x2_t a = *reinterpret_cast<const f64x2_t *>(qs + k0 + 2 * i);
+                double d;
+                d = a.x - v[i].x; s = s + d * d;
+                d = a.y - v[i].y; s = s + d * d;
+            }
+        }
+    }
+    return sqrt(s);
+}
+// k-th smallest (1-based) of n LDS keys of either width
+template <typename KeyT>
+__device__ __forceinline__ KeyT kth_smallest_keys(const KeyT *a, uint32_t n, uint32_t k, int lane) {
+    if constexpr (sizeof(KeyT) == 4) {
+        return (KeyT)kth_smallest_lds(reinterpret_cast<const uint32_t *>(a), n, k, lane);
+    } else {
+        KeyT Tk = 0;
+        for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
+            const KeyT cand = Tk | ((KeyT)1 << b);
+            uint32_t c = 0;
+            for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                c += (uint32_t)__popcll(__ballot(e < n && a[e] < cand));
+            }
+            if (c < k) Tk = cand;
+        }
+        return Tk;
+    }
+}
+// The proof's two sides (header of this section).  rhs: everything at or below it may still round to d_k (key kk, finite,
+// >= +0) and tie; lb: lower bound of the REFERENCE's folded sum for a row whose bound of d2 - |q|^2 is L (tagged: within
+// 2^-19 of the bound itself), qadd <= |q|^2.
+//   f32 distances: the sides are evaluated in f64, 29 bits to spare;
+//   f64 distances: the same inequalities with u = 2^-53, evaluated in f64 itself, so each side is pushed outward by a few
+//     ulp for its own roundings -- rhs = succ(d_k)^2 (1 + 2^-51) >= ((d_k + succ d_k) / 2)^2, lb times (1 - 2^-50).
+template <typename T> __device__ __forceinline__ double proof_rhs(typename KeyOf<T>::type kk);
+template <> __device__ __forceinline__ double proof_rhs<float>(uint32_t kk) {
+    const double dk = (double)__uint_as_float(kk), dn = (double)__uint_as_float(kk + 1);  // succ(d_k): next float up
+    const double mid = 0.5 * (dk + dn);
+    return mid * mid * (1.0 + 4.5e-16);
+}
+template <> __device__ __forceinline__ double proof_rhs<double>(uint64_t kk) {
+    const double dn = __longlong_as_double((long long)(kk + 1));  // succ(d_k)
+    return dn * dn * (1.0 + 4.440892098500626e-16);
+}
+template <typename T> __device__ __forceinline__ double proof_lb(double L, double qadd, int dim);
+template <> __device__ __forceinline__ double proof_lb<float>(double L, double qadd, int dim) {
+    return ((L - fabs(L) * 1.9073486328125e-06) + qadd) * (1.0 - (double)(dim + 4) * 5.9604644775390625e-08) - 1e-37;
+}
+template <> __device__ __forceinline__ double proof_lb<double>(double L, double qadd, int dim) {
+    return ((L - fabs(L) * 1.9073486328125e-06) + qadd) * (1.0 - (double)(dim + 4) * 1.1102230246251565e-16) *
+               (1.0 - 8.881784197001252e-16) - 1e-300;
+}
+
 #ifdef PN_DIAG_RR_STAMP  // diagnostic build only: where a re-rank wave's time goes (cycle sums per phase)
 // per-query phase durations [16384][8], written once per wave at its end (an atomic per phase on a shared counter
 // would itself be what the waves wait for)
@@ -334,16 +419,20 @@ extern "C" int pn_debug_read_rr(unsigned long long *out, int nq) {
 #else
 #define RR_STAMP(i) ((void)0)
 #endif
+template <typename T>
 __global__ __launch_bounds__(64) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
-    size_t nq_pad, int nseg, int cap, const float *__restrict__ P, size_t ldp, const float *__restrict__ Q,
+    size_t nq_pad, int nseg, int cap, const T *__restrict__ P, size_t ldp, const T *__restrict__ Q,
     size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
-    float *__restrict__ dist_out, size_t out_stride, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
+    T *__restrict__ dist_out, size_t out_stride, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
     const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
     int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ sel,
     unsigned long long *__restrict__ stats, uint32_t first_eval) {
+    using KeyT = typename KeyOf<T>::type;
+    constexpr KeyT KMAX = KeyOf<T>::kMax;                       // an entry whose distance has not been evaluated
+    const KeyT KINF = sel_key((T)__builtin_huge_val());        // key of +inf: keys at or above it are inf / NaN
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t kth_key;
+    __shared__ KeyT kth_key;
     __shared__ uint32_t seg_off[65], seg_cnt[64];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
@@ -372,13 +461,16 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     }
     const float min_tau = __uint_as_float((min_key & 0x80000000u) ? (min_key & 0x7FFFFFFFu) : ~min_key);
     RR_STAMP(0);  // counts + thresholds read and reduced
-    uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *sidx = skey + total_cap;
-    uint32_t *sfk = sidx + total_cap;  // the filter's keys (when given)
-    float *qs = reinterpret_cast<float *>(sfk + total_cap);  // the query row, zero padded like the corpus rows
-    if (lane == 0) kth_key = KeyOf<float>::kNaN;
-    const float *qrow = Q + q * ldq;
+    // LDS: the query row FIRST (zero padded like the corpus rows; its 16-byte reads need a 16-byte aligned base -- behind
+    // arrays of total_cap entries it was misaligned for three counts in four, and a misaligned ds_read_b128 is replayed),
+    // then the exact keys, the rows, the filter's keys
     const int len = (int)((dim + 7) / 8 * 8);  // <= ldp, ldq: both are padded to a multiple of 8 with zeros
+    T *qs = reinterpret_cast<T *>(smem);
+    KeyT *skey = reinterpret_cast<KeyT *>(qs + len);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(skey + total_cap);
+    uint32_t *sfk = sidx + total_cap;  // the filter's keys (when given)
+    if (lane == 0) kth_key = KeyOf<T>::kNaN;
+    const T *qrow = Q + q * ldq;
     for (int k = lane; k < len; k += 64) qs[k] = qrow[k];
     const double u = 5.9604644775390625e-08;  // 2^-24
     uint32_t n = 0, evaluated = 0;
@@ -425,7 +517,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
                     if (e < chunk_total) {
                         sidx[n + e] = ixr[r];
                         sfk[n + e] = fkr[r];
-                        skey[n + e] = 0xFFFFFFFFu;
+                        skey[n + e] = KMAX;
                     }
                 }
             }
@@ -442,7 +534,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
                 const uint32_t ix = cidx[src];
                 sidx[n + e] = ix;
                 // a row number beyond the corpus (never produced; defensive) sorts behind everything
-                skey[n + e] = ix < n_rows ? sel_key(exact_distance_f32(qrow, P + (size_t)ix * ldp, dim)) : 0xFFFFFFFFu;
+                skey[n + e] = ix < n_rows ? sel_key(exact_distance_seq<T>(qrow, P + (size_t)ix * ldp, dim)) : KMAX;
             }
         }
         n += chunk_total;
@@ -469,35 +561,31 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
             const bool go = e < n && (all || sfk[e] <= K1);
             if (go) {
                 const uint32_t ix = sidx[e];
-                if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched_f32(qs, P + (size_t)ix * ldp, len));
+                if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
             }
             evaluated += (uint32_t)__popcll(__ballot(go));
         }
         __syncthreads();
         RR_STAMP(3);  // first evaluation round
         if (!all) {
-            const uint32_t dk1 = kth_smallest_lds(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
+            const KeyT dk1 = kth_smallest_keys<KeyT>(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
             RR_STAMP(4);  // k-th smallest exact distance so far
-            const bool prune = dk1 < 0x7F800000u;  // finite: else every candidate is evaluated
+            const bool prune = dk1 < KINF;  // finite: else every candidate is evaluated
             double rhs = 0.0;
-            if (prune) {
-                const double dk = (double)__uint_as_float(dk1), dn = (double)__uint_as_float(dk1 + 1);
-                const double mid = 0.5 * (dk + dn);
-                rhs = mid * mid * (1.0 + 4.5e-16);
-            }
+            if (prune) rhs = proof_rhs<T>(dk1);
             const double qadd = qn ? qn[q] : 0.0;
             for (uint32_t e0 = 0; e0 < n; e0 += 64) {
                 const uint32_t e = e0 + lane;
-                bool go = e < n && skey[e] == 0xFFFFFFFFu && sfk[e] > K1;
+                bool go = e < n && skey[e] == KMAX && sfk[e] > K1;
                 if (go && prune) {
                     const uint32_t fk = sfk[e];
                     const double L = (double)__uint_as_float((fk & 0x80000000u) ? (fk & 0x7FFFFFFFu) : ~fk);
-                    const double lb = ((L - fabs(L) * 1.9073486328125e-06) + qadd) * (1.0 - (double)(dim + 4) * u) - 1e-37;
+                    const double lb = proof_lb<T>(L, qadd, dim);
                     go = !(lb > rhs);  // not provably farther than the kout-th exact distance found so far
                 }
                 if (go) {
                     const uint32_t ix = sidx[e];
-                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched_f32(qs, P + (size_t)ix * ldp, len));
+                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
                 }
                 evaluated += (uint32_t)__popcll(__ballot(go));
             }
@@ -512,9 +600,9 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         uint32_t w = 0;
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
-            const uint32_t k = e < n ? skey[e] : 0xFFFFFFFFu;
+            const KeyT k = e < n ? skey[e] : KMAX;
             const uint32_t ix = e < n ? sidx[e] : 0u;
-            const bool keep = k != 0xFFFFFFFFu;
+            const bool keep = k != KMAX;
             const unsigned long long m = __ballot(keep);
             const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (keep) {
@@ -526,13 +614,13 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         n = w;
         __syncthreads();
     }
-    n = prune_to_topk<uint32_t, uint32_t>(skey, sidx, n, (uint32_t)kout, lane);
+    n = prune_to_topk<KeyT, uint32_t>(skey, sidx, n, (uint32_t)kout, lane);
     __syncthreads();
     RR_STAMP(6);  // cut to the k smallest
     for (uint32_t e = lane; e < n; e += 64) {
-        const uint32_t k = skey[e];
+        const KeyT k = skey[e];
         const uint32_t ix = sidx[e];
-        const uint32_t r = rank_of<uint32_t, uint32_t>(skey, sidx, n, k, ix);
+        const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
             idx_out[q * out_stride + r] = index_base + ix;
             dist_out[q * out_stride + r] = key_to_dist(k);
@@ -551,18 +639,14 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
 #endif
     if (lane == 0) {
         bool ok = n_all >= (uint32_t)kout;
-        const uint32_t kk = kth_key;
-        if (ok && kk >= 0x7F800000u) ok = false;  // k-th distance is inf/NaN: let the exact engine order it
+        const KeyT kk = kth_key;
+        if (ok && kk >= KINF) ok = false;  // k-th distance is inf/NaN: let the exact engine order it
         if (ok && min_tau < __uint_as_float(0x7F800000u)) {
-            const double dk = (double)__uint_as_float(kk);
-            const double dn = (double)__uint_as_float(kk + 1);  // succ(d_k): next float up (d_k finite, >= +0)
-            const double mid = 0.5 * (dk + dn);
-            const double rhs = mid * mid * (1.0 + 4.5e-16);
+            const double rhs = proof_rhs<T>(kk);
             // bf16 filter: the thresholds are TAGGED bounds of d2 - |q|^2 (bf16_filter.hip): within 2^-19 relative
             // of the bound itself; qn[q] <= |q|^2
-            const double d2_lb = qn ? ((double)min_tau - fabs((double)min_tau) * 1.9073486328125e-06) + qn[q]
-                                    : (double)min_tau;
-            const double lb = d2_lb * (1.0 - (double)(dim + 4) * u) - 1e-37;
+            const double lb = qn ? proof_lb<T>((double)min_tau, qn[q], dim)
+                                 : (double)min_tau * (1.0 - (double)(dim + 4) * u) - 1e-37;
             ok = (min_tau == min_tau) && (lb > rhs);
         }
         if (qbad && qbad[q]) ok = false;
@@ -582,23 +666,43 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     }
 }
 
-hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
-                                    const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
-                                    uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
-                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
-                                    unsigned long long *stats, hipStream_t s, int first_eval, int cell_max) {
+template <typename T>
+static hipError_t launch_select_rerank(const CandBuf &cb, const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq,
+                                       size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out, T *dist_out,
+                                       size_t out_stride, uint32_t *flags, uint32_t *n_flagged, const double *qn,
+                                       const uint32_t *qbad, uint32_t *sel, unsigned long long *stats, hipStream_t s,
+                                       int first_eval, int cell_max) {
+    using KeyT = typename KeyOf<T>::type;
     // with filter keys in the buffers (both MFMA tiers) candidates are evaluated lazily
     const uint32_t *ckey = static_cast<const uint32_t *>(cb.keys);
     // LDS for what the cells can HOLD (cell_max entries each: the filter's k' after its final cut), not for their
     // capacity: C2 12 x 13 entries = 1.9 KB instead of 9.2 KB, and the waves per CU are no longer set by LDS
     const size_t per_cell = cell_max > 0 && cell_max < cb.cap ? (size_t)cell_max : (size_t)cb.cap;
-    const size_t sh = (size_t)cb.nseg * per_cell * 12 + ((size_t)dim + 8) * sizeof(float);
+    const size_t sh = (size_t)cb.nseg * per_cell * (sizeof(KeyT) + 8) + ((size_t)dim + 8) * sizeof(T);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(64), sh, s,
+    hipLaunchKernelGGL(select_rerank_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
                        ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, out_stride, flags, n_flagged, qn,
                        qbad, cb.idx_stride, ckey, sel, stats, (uint32_t)(first_eval > 0 ? first_eval : 0));
     return hipGetLastError();
+}
+hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
+                                    const float *Q, int nq, size_t ldq, int kout, uint64_t index_base,
+                                    uint64_t *idx_out, float *dist_out, size_t out_stride, uint32_t *flags,
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
+                                    unsigned long long *stats, hipStream_t s, int first_eval, int cell_max) {
+    return launch_select_rerank<float>(cb, P, n, dim, ldp, Q, nq, ldq, kout, index_base, idx_out, dist_out, out_stride,
+                                       flags, n_flagged, qn, qbad, sel, stats, s, first_eval, cell_max);
+}
+// f64 indexes behind the bf16 filter: the candidates' distances in the reference's f64 fold, the proof with u = 2^-53
+hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp,
+                                    const double *Q, int nq, size_t ldq, int kout, uint64_t index_base,
+                                    uint64_t *idx_out, double *dist_out, size_t out_stride, uint32_t *flags,
+                                    uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
+                                    unsigned long long *stats, hipStream_t s, int first_eval, int cell_max) {
+    if (!qn) return hipErrorInvalidValue;  // (only the bf16 tier serves f64)
+    return launch_select_rerank<double>(cb, P, n, dim, ldp, Q, nq, ldq, kout, index_base, idx_out, dist_out, out_stride,
+                                        flags, n_flagged, qn, qbad, sel, stats, s, first_eval, cell_max);
 }
 
 // ---------------------------------------------------------------------------
