@@ -2470,11 +2470,15 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
 // segment than each segment's own list could give (rank from the host: the sample holds Poisson(lambda) of the rows
 // that matter, the seed must stay above them).  out[q] = sortable key just above that bound.  One wave per query.
 __global__ __launch_bounds__(64) void bf16_seed_kernel(const float *__restrict__ lists, size_t nq_pad, int nseg,
-                                                       uint32_t rank, uint32_t *__restrict__ out) {
+                                                       uint32_t rank, uint32_t *__restrict__ out, size_t nq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *sk = reinterpret_cast<uint32_t *>(smem_raw);
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
+    if (q >= nq) {  // a padding query of the last tile: nothing passes its threshold (-inf), so it costs no appends
+        if (lane == 0) out[q] = f2s(__uint_as_float(0xFF800000u));
+        return;
+    }
     const uint32_t per = 2 * kScoutList, n = (uint32_t)nseg * per;
     uint32_t T = 0;
     if (n <= 512u) {  // up to eight words per lane, in registers: no LDS round trip per bit (C2: 288 values per query)
@@ -2494,26 +2498,58 @@ __global__ __launch_bounds__(64) void bf16_seed_kernel(const float *__restrict__
         if (lane == 0) out[q] = T == 0xFFFFFFFFu ? T : T + 1;
         return;
     }
-    for (uint32_t e = lane; e < n; e += 64)
-        sk[e] = f2s(lists[((size_t)(e / per) * nq_pad + q) * per + e % per]);
+    // Many segments (a handful of queries spread over every workgroup slot: 512 segments x 24 values): a radix select
+    // over all n values in LDS is 32 x n/64 dependent LDS round trips -- 0.3 ms for ONE query's wave.  Instead: the
+    // rank-th smallest of the 64 lanes' minima is an upper bound U of the answer (rank lanes hold a value at or below
+    // it, rank <= 24 < 64); only the values at or below U -- a few times rank of them -- go to LDS and are selected from.
+    // (every (segment, lane half) list is sorted ascending: its first entry is its minimum, and the entries at or below
+    // U are a prefix -- a lane walks its lists' heads, 2 nseg / 64 loads, instead of all n values)
+    const uint32_t n_lists = 2u * (uint32_t)nseg;
+    auto list_at = [&](uint32_t li) { return lists + ((size_t)(li >> 1) * nq_pad + q) * per + (size_t)(li & 1u) * kScoutList; };
+    uint32_t lmin = 0xFFFFFFFFu;
+    for (uint32_t li = lane; li < n_lists; li += 64) {
+        const uint32_t v = f2s(list_at(li)[0]);
+        lmin = v < lmin ? v : lmin;
+    }
+    uint32_t U = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cnd = U | (1u << bit);
+        if ((uint32_t)__popcll(__ballot(lmin < cnd)) < rank) U = cnd;
+    }
+    __shared__ uint32_t s_w;
+    if (lane == 0) s_w = 0u;
     __syncthreads();
+    const uint32_t cap_lds = (uint32_t)nseg * per;  // (the launch sized LDS for all n values)
+    for (uint32_t li = lane; li < n_lists; li += 64) {
+        const float *l = list_at(li);
+        for (int i = 0; i < kScoutList; ++i) {
+            const uint32_t v = f2s(l[i]);
+            if (v > U) break;
+            const uint32_t pos = atomicAdd(&s_w, 1u);
+            if (pos < cap_lds) sk[pos] = v;
+        }
+    }
+    __syncthreads();
+    const uint32_t w = s_w;
+    const uint32_t nn = w < cap_lds ? w : cap_lds;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cnd = T | (1u << bit);
         uint32_t c = 0;
-        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        for (uint32_t e0 = 0; e0 < nn; e0 += 64) {
             const uint32_t e = e0 + lane;
-            c += (uint32_t)__popcll(__ballot(e < n && sk[e] < cnd));
+            c += (uint32_t)__popcll(__ballot(e < nn && sk[e] < cnd));
         }
         if (c < rank) T = cnd;
     }
     if (lane == 0) out[q] = T == 0xFFFFFFFFu ? T : T + 1;  // rows with a bound EQUAL to it still pass the strict '<'
 }
 
-hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s) {
+hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s,
+                            size_t nq) {
     const size_t sh = (size_t)nseg * 2 * kScoutList * sizeof(uint32_t);
     if (sh > 64 * 1024 || rank < 1 || (size_t)rank > (size_t)nseg * 2 * kScoutList) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bf16_seed_kernel, dim3((unsigned)nq_pad), dim3(64), sh, s, lists, nq_pad, nseg, (uint32_t)rank,
-                       out);
+                       out, nq ? nq : nq_pad);
     return hipGetLastError();
 }
 int bf16_scout_list() { return kScoutList; }

@@ -136,6 +136,23 @@ struct Workspace {
     DevBuf w_bq, w_qn, w_qbad, w_gq, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
     DevBuf w_hq, w_hidx, w_hdist;  // staging of the host entry points (queries up, results down)
     DevBuf w_fparts;               // second tier, many-segment path: per-group partial results
+    // small calls (tiny_*): mapped pinned host memory the one kernel of the call reads its queries from and writes its
+    // answers to -- no copy commands
+    void *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    int pin_ensure(void **p, size_t *have, size_t need) {
+        if (need <= *have && *p) return PN_OK;
+        if (*p) {
+            (void)hipStreamSynchronize(stream);  // (host entry points wait for their stream: nothing of ours is in flight)
+            (void)hipHostFree(*p);
+        }
+        *p = nullptr;
+        *have = 0;
+        const size_t want = need + need / 2 + 4096;
+        if (hipHostMalloc(p, want, hipHostMallocMapped) != hipSuccess) return fail(PN_ERR_NOMEM, "hipHostMalloc(%zu) failed", want);
+        *have = want;
+        return PN_OK;
+    }
     DevBuf w_pcnt;                 // shared thresholds: the segments' published fill counts [nseg][nq_pad]
     uint32_t sh_epoch = 0;         // epoch of the last launch that published into w_pcnt (1 .. 4095)
     size_t sh_nseg = 0, sh_nq_pad = 0;  // geometry w_pcnt was last used with (a change: zero it once)
@@ -496,6 +513,8 @@ extern "C" void pn_index_destroy(pn_index *ix) {
         ws->free_retired();
         for (hipEvent_t e : ws->ev_r)
             if (e) (void)hipEventDestroy(e);
+        if (ws->pin_in) (void)hipHostFree(ws->pin_in);
+        if (ws->pin_out) (void)hipHostFree(ws->pin_out);
         if (ws->done) (void)hipEventDestroy(ws->done);
         if (ws->stream) (void)hipStreamDestroy(ws->stream);
         delete ws;
@@ -1107,12 +1126,21 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
     size_t n_wg = 2 * (size_t)ix->n_cu;
     size_t cap_wg = q_tiles * 32;  // at most ~32 workgroups per query tile, at least ~32 row tiles each
-    const size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    size_t by_work = (q_tiles * r_tiles + 31) / 32;
+    // A handful of queries (one or two query tiles: the reference's one-point-per-call pattern against a large corpus) is
+    // HBM-bound -- the image is streamed once whatever the batch -- and 32 workgroups stream it at a sixteenth of the
+    // chip's rate (round 2: 621 us for one query against 1M x 128).  So few query tiles take a workgroup per CU, down to
+    // runs of 16 row tiles (measured, one query per call, host API: 32 segments 621 us, 128: 185, 256: 145, 512: 202 --
+    // beyond one per CU the re-rank's walk over the segments costs more than the shorter runs save).
+    if (q_tiles <= 2) {
+        cap_wg = (size_t)ix->n_cu / q_tiles * q_tiles;
+        by_work = (q_tiles * r_tiles + 15) / 16;
+    }
     if (by_work < cap_wg) cap_wg = by_work;
     if (ix->opt_segments > 0 && q_tiles * (size_t)ix->opt_segments < cap_wg) cap_wg = q_tiles * (size_t)ix->opt_segments;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
-    n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);
+    if (q_tiles > 2) n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);  // (many query tiles: a grid run in rounds)
     // a whole number of workgroups per query tile: each workgroup's slice is then ONE run.  A slice that straddles
     // a query-tile boundary is two runs, each with its own operand load, scout pass and buffer warm-up, and those
     // workgroups set the kernel's time (C2: 512 workgroups = 12.8 per tile 4.34 ms, 480 = 12 per tile 3.62 ms)
@@ -1171,7 +1199,8 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         if (t > 64.0) t = 64.0;
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
         p.scout_tiles = (int)t;
-        if (p.scout_tiles >= 4) {
+        if (p.scout_tiles < 1 && run_len >= 8) p.scout_tiles = 1;  // short runs of many segments: one tile each is a large sample
+        if (p.scout_tiles >= 4 || (p.scout_tiles >= 1 && run_len < 64)) {
             const double lam = R * (double)p.scout_tiles * (double)per_tile / (double)r_tiles;
             double term = std::exp(-lam), cdf = term;  // P(X <= 0)
             int rank = 1;
@@ -1329,7 +1358,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
         else
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
                                       nullptr, false, (float *)ws.w_lists.p, ix->bf16_ci, s));
-        HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s));
+        HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s, nq));
         if (plan.wide)
             HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg, 0,
                                            (const uint32_t *)ws.w_seed.p, false, nullptr, s));
@@ -1545,6 +1574,88 @@ static int upload_rows(const T *h, size_t rows, size_t cols, ptrdiff_t row_strid
 // Host entry point: what the reference's one-point-per-call API maps to (src/ball_tree.rs:102; nq = 1 is that call).
 // Staging buffers come from the workspace (no allocation per call once warm); the call runs on the workspace's own
 // stream, so host threads sharing one handle do not serialise each other.
+// ---- small corpora, a few queries per call: the reference's own call pattern (one point per BallTree::query /
+// query_radius call, benches/ball_tree.rs:22-62).  The batched pipeline costs such a call a dozen launches and three copy
+// commands (round 2: 72 us against the CPU's 19 us at 64 x 10 f64); here the call is ONE launch that reads the query from
+// mapped pinned memory, scans the rows with one wave per query (select.hip, tiny_query_kernel) and writes the answer to
+// mapped pinned memory, and one wait for the stream.
+constexpr size_t kTinyRows = 4096, kTinyQueries = 64;
+template <typename T>
+static bool tiny_eligible(const pn_index *ix, size_t nq, size_t dim_eff) {
+    return ix->metric == 0 && ix->n <= kTinyRows && nq <= kTinyQueries &&
+           (ix->engine == PN_ENGINE_AUTO || ix->engine == PN_ENGINE_EXACT) &&
+           ix->n * (dim_eff ? dim_eff : 1) * nq <= ((size_t)1 << 22) &&  // (beyond: the tiled engine's parallelism pays)
+           tiny_query_lds_bytes(ix->n, (int)dim_eff, (int)sizeof(T)) <= 64 * 1024;
+}
+template <typename T>
+static hipError_t tiny_launch(const pn_index *ix, size_t dim_eff, const T *Qd, size_t ldq, size_t nq, size_t kout, bool rad,
+                              T radius, uint64_t *io, T *dd, size_t os, hipStream_t s) {
+    if constexpr (sizeof(T) == 4)
+        return launch_tiny_query_f32((const float *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qd, ldq, (int)nq, (int)kout, rad,
+                                     radius, ix->index_base, io, dd, os, s);
+    else
+        return launch_tiny_query_f64((const double *)ix->d_pts, ix->n, (int)dim_eff, ix->ld, Qd, ldq, (int)nq, (int)kout, rad,
+                                     radius, ix->index_base, io, dd, os, s);
+}
+// stages the queries in the workspace's pinned input buffer; *Qd = its device address
+template <typename T>
+static int tiny_stage(Workspace &ws, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, const T **Qd) {
+    const size_t qc = q_cols ? q_cols : 1;
+    PNCHK(ws.pin_ensure(&ws.pin_in, &ws.pin_in_bytes, nq * qc * sizeof(T)));
+    T *h = (T *)ws.pin_in;
+    for (size_t a = 0; a < nq; ++a)
+        if (q_cols) memcpy(h + a * qc, q + (ptrdiff_t)a * q_stride, q_cols * sizeof(T));
+    void *d = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&d, ws.pin_in, 0));
+    *Qd = (const T *)d;
+    return PN_OK;
+}
+template <typename T>
+static int tiny_knn(const pn_index *ix, Workspace &ws, hipStream_t s, const T *q, size_t nq, size_t q_cols,
+                    ptrdiff_t q_stride, size_t kout, uint64_t *idx_out, T *dist_out) {
+    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim, qc = q_cols ? q_cols : 1;
+    const T *Qd = nullptr;
+    PNCHK(tiny_stage<T>(ws, q, nq, q_cols, q_stride, &Qd));
+    const size_t ib = nq * kout * sizeof(uint64_t), db = nq * kout * sizeof(T);
+    PNCHK(ws.pin_ensure(&ws.pin_out, &ws.pin_out_bytes, ib + db));
+    void *od = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&od, ws.pin_out, 0));
+    HIPCHK(tiny_launch<T>(ix, dim_eff, Qd, qc, nq, kout, false, (T)0, (uint64_t *)od, (T *)((char *)od + ib), kout, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(idx_out, ws.pin_out, ib);
+    memcpy(dist_out, (char *)ws.pin_out + ib, db);
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    ix->sh.stats.queries += nq;
+    return PN_OK;
+}
+template <typename T>
+static int tiny_radius(const pn_index *ix, Workspace &ws, hipStream_t s, const T *q, size_t nq, size_t q_cols,
+                       ptrdiff_t q_stride, T radius, uint64_t *offsets, uint64_t **idx_out) {
+    const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim, qc = q_cols ? q_cols : 1;
+    const T *Qd = nullptr;
+    PNCHK(tiny_stage<T>(ws, q, nq, q_cols, q_stride, &Qd));
+    const size_t os = ix->n + 1;  // per query: count, then up to n rows
+    PNCHK(ws.pin_ensure(&ws.pin_out, &ws.pin_out_bytes, nq * os * sizeof(uint64_t)));
+    void *od = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&od, ws.pin_out, 0));
+    HIPCHK(tiny_launch<T>(ix, dim_eff, Qd, qc, nq, 0, true, radius, (uint64_t *)od, (T *)nullptr, os, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t *h = (const uint64_t *)ws.pin_out;
+    uint64_t total = 0;
+    for (size_t a = 0; a < nq; ++a) {
+        offsets[a] = total;
+        total += h[a * os];
+    }
+    offsets[nq] = total;
+    uint64_t *out = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+    if (!out) return fail(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)total);
+    for (size_t a = 0; a < nq; ++a) memcpy(out + offsets[a], h + a * os + 1, (size_t)h[a * os] * sizeof(uint64_t));
+    *idx_out = out;
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    ix->sh.stats.radius_results += total;
+    return PN_OK;
+}
+
 template <typename T>
 static int query_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_cols, ptrdiff_t q_stride, size_t k,
                            uint64_t *idx_out, T *dist_out) {
@@ -1561,6 +1672,24 @@ static int query_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_c
     PNCHK(ws_acquire(ix, &lease.s, true, &lease.ws));
     Workspace &ws = *lease.ws;
     hipStream_t s = lease.s;
+    if (q_stride >= 0 && tiny_eligible<T>(ix, nq, q_cols < ix->dim ? q_cols : ix->dim))
+        return tiny_knn<T>(ix, ws, s, q, nq, q_cols, q_stride, kout, idx_out, dist_out);
+    // a small batch against a large corpus: the kernels read the queries from, and write the answers to, mapped pinned
+    // memory -- three copy commands (~10 us each) less on a call whose whole GPU time is ~100 us
+    if (q_stride >= 0 && nq * (q_cols ? q_cols : 1) * sizeof(T) <= (64u << 10) && nq * kout * 16 <= (64u << 10)) {
+        const T *Qd = nullptr;
+        PNCHK(tiny_stage<T>(ws, q, nq, q_cols, q_stride, &Qd));
+        const size_t ib = nq * kout * sizeof(uint64_t), db = nq * kout * sizeof(T);
+        PNCHK(ws.pin_ensure(&ws.pin_out, &ws.pin_out_bytes, ib + db));
+        void *od = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&od, ws.pin_out, 0));
+        PNCHK(query_enqueue<T>(ix, ws, Qd, nq, q_cols, q_cols ? q_cols : 1, kout, (uint64_t *)od, (T *)((char *)od + ib),
+                               kout, s));
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(idx_out, ws.pin_out, ib);
+        memcpy(dist_out, (char *)ws.pin_out + ib, db);
+        return PN_OK;
+    }
     PNCHK(upload_rows_to<T>(q, nq, q_cols, q_stride, ws.w_hq, s));
     PNCHK(ws.w_hidx.ensure(nq * kout * sizeof(uint64_t)));
     PNCHK(ws.w_hdist.ensure(nq * kout * sizeof(T)));
@@ -1985,6 +2114,8 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
         level = ix->sh.bf16_level;
     }
     const size_t dim_eff = q_cols < ix->dim ? q_cols : ix->dim;
+    if (q_stride >= 0 && tiny_eligible<T>(ix, nq, dim_eff))
+        return tiny_radius<T>(ix, ws, s, q, nq, q_cols, q_stride, radius, offsets, idx_out);
     const size_t nq_pad = round_up(nq, (size_t)256);
     int rc = upload_rows_to<T>(q, nq, q_cols, q_stride, ws.w_hq, s);
     do {

@@ -141,6 +141,15 @@ hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n
                                     unsigned long long *stats, hipStream_t s, int first_eval = 0, int cell_max = 0);
 // osel (nullable): the merged result of query q goes to row osel[q] of the outputs (row stride out_stride, 0 = k_out);
 // host_count (nullable, mapped pinned memory): block 0 copies *nq_dev there (the count a LATER call looks at)
+// Small corpora, a few queries per call: the whole call in one launch (one wave per query over all rows); Q and the
+// outputs may be mapped pinned host memory.  radius_mode: out row q = {count, rows ascending ...} (out_stride >= n + 1)
+size_t tiny_query_lds_bytes(size_t n, int dim_eff, int elem_bytes);  // must be <= 64 KiB
+hipError_t launch_tiny_query_f32(const float *P, size_t n, int dim_eff, size_t ldp, const float *Q, size_t ldq, int nq,
+                                 int kout, bool radius_mode, float radius, uint64_t index_base, uint64_t *idx_out,
+                                 float *dist_out, size_t out_stride, hipStream_t s);
+hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t ldp, const double *Q, size_t ldq, int nq,
+                                 int kout, bool radius_mode, double radius, uint64_t index_base, uint64_t *idx_out,
+                                 double *dist_out, size_t out_stride, hipStream_t s);
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
@@ -262,7 +271,9 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
 int bf16_scout_list();
 int bf16_cell_max(int kp, int cap);  // entries a cell holds at most after a k-NN launch (its final cut to k')
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
-hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s);
+// nq (0: nq_pad): the queries beyond it are padding and get the threshold -inf
+hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s,
+                            size_t nq = 0);
 hipError_t launch_bf16_radius_tau(const double *qn, size_t nq_pad, double tau_r, uint32_t *out, hipStream_t s);
 // diagnostic: out[q][row] = L'(q, row), q < nq, row < n_rows
 hipError_t launch_bf16_bound(const void *img, const void *B, size_t n_rows, size_t nq, int dim, float *out, bool ci,

@@ -706,6 +706,119 @@ hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n
 }
 
 // ---------------------------------------------------------------------------
+// Small corpora, a point (or a few) per call -- the reference's own call pattern (benches/ball_tree.rs:22-62: 64 x 10
+// f64, BallTree::query / query_radius once per point): ONE launch is the whole call.  One wave per query: the lanes
+// fold their rows' distances in the reference's order (Euclidean::distance, src/distance.rs:26-35), keys go to LDS;
+// k-NN: the kout smallest under (key, row) -- the same selection and ranking as the exact engine's; radius: the rows
+// with distance < r (strict, src/ball_tree.rs:277) in ascending order.  The query is read from, and the answer written
+// to, mapped pinned host memory: no copy commands, the host waits for its stream once (index.hip, tiny_*).
+// Radius output of query q: out[q * out_stride] = count, then the rows.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void tiny_query_kernel(const T *__restrict__ P, uint32_t n, int dim_eff, size_t ldp,
+                                                        const T *__restrict__ Q, size_t ldq, int kout, int radius_mode,
+                                                        T radius, uint64_t index_base, uint64_t *__restrict__ idx_out,
+                                                        T *__restrict__ dist_out, size_t out_stride) {
+    using KeyT = typename KeyOf<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const int lenq = (dim_eff + 7) / 8 * 8;
+    T *qs = reinterpret_cast<T *>(smem);
+    KeyT *skey = reinterpret_cast<KeyT *>(qs + lenq);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(skey + n);
+    for (int k = lane; k < lenq; k += 64) qs[k] = k < dim_eff ? Q[q * ldq + k] : (T)0;
+    __syncthreads();
+    if (radius_mode) {
+        uint32_t cnt = 0;
+        uint64_t *out = idx_out + q * out_stride;
+        for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+            const uint32_t r = r0 + (uint32_t)lane;
+            bool in = false;
+            if (r < n) in = exact_distance_seq<T>(qs, P + (size_t)r * ldp, dim_eff) < radius;
+            const unsigned long long m = __ballot(in);
+            if (in) out[1 + cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = index_base + r;
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) out[0] = cnt;
+        return;
+    }
+    KeyT lmin = KeyOf<T>::kMax;  // this lane's smallest key
+    for (uint32_t r = lane; r < n; r += 64) {
+        const KeyT kk = sel_key(exact_distance_seq<T>(qs, P + (size_t)r * ldp, dim_eff));
+        skey[r] = kk;
+        sidx[r] = r;
+        lmin = kk < lmin ? kk : lmin;
+    }
+    __syncthreads();
+    uint32_t n_in = n;
+    if (n > 256u && kout <= 32) {
+        // Cut before selecting: the kout-th smallest of the 64 lanes' minima is an upper bound of the kout-th smallest key
+        // (kout lanes hold a key at or below it), found on one register per lane; the keys at or below it -- a few times
+        // kout of them -- are moved to the front (stable), and the general selection (a radix select over LDS, ~100
+        // cycles per 64 keys and bit: 45 us at n = 1000 with 64-bit keys) runs over those only.
+        KeyT Tm = 0;
+        for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
+            const KeyT cand = Tm | ((KeyT)1 << b);
+            if ((uint32_t)__popcll(__ballot(lmin < cand)) < (uint32_t)kout) Tm = cand;
+        }
+        uint32_t w = 0;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            const KeyT kk = e < n ? skey[e] : KeyOf<T>::kMax;
+            const uint32_t ix = e < n ? sidx[e] : 0u;
+            const bool keep = e < n && kk <= Tm;
+            const unsigned long long mm = __ballot(keep);
+            const uint32_t pos = w + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+            if (keep) {
+                skey[pos] = kk;
+                sidx[pos] = ix;
+            }
+            w += (uint32_t)__popcll(mm);
+        }
+        n_in = w;
+        __syncthreads();
+    }
+    const uint32_t m = prune_to_topk<KeyT, uint32_t>(skey, sidx, n_in, (uint32_t)kout, lane);
+    __syncthreads();
+    for (uint32_t e = lane; e < m; e += 64) {
+        const KeyT k = skey[e];
+        const uint32_t ix = sidx[e];
+        const uint32_t rk = rank_of<KeyT, uint32_t>(skey, sidx, m, k, ix);
+        if (rk < (uint32_t)kout) {
+            idx_out[q * out_stride + rk] = index_base + ix;
+            dist_out[q * out_stride + rk] = key_to_dist(k);
+        }
+    }
+}
+template <typename T>
+static hipError_t launch_tiny_query(const T *P, size_t n, int dim_eff, size_t ldp, const T *Q, size_t ldq, int nq,
+                                    int kout, bool radius_mode, T radius, uint64_t index_base, uint64_t *idx_out,
+                                    T *dist_out, size_t out_stride, hipStream_t s) {
+    using KeyT = typename KeyOf<T>::type;
+    const size_t sh = (size_t)((dim_eff + 7) / 8 * 8) * sizeof(T) + n * (sizeof(KeyT) + sizeof(uint32_t));
+    if (sh > 64 * 1024 || n == 0 || n > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tiny_query_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s, P, (uint32_t)n, dim_eff, ldp, Q, ldq, kout,
+                       radius_mode ? 1 : 0, radius, index_base, idx_out, dist_out, out_stride);
+    return hipGetLastError();
+}
+size_t tiny_query_lds_bytes(size_t n, int dim_eff, int elem_bytes) {
+    return (size_t)((dim_eff + 7) / 8 * 8) * (size_t)elem_bytes + n * ((size_t)elem_bytes + 4);
+}
+hipError_t launch_tiny_query_f32(const float *P, size_t n, int dim_eff, size_t ldp, const float *Q, size_t ldq, int nq,
+                                 int kout, bool radius_mode, float radius, uint64_t index_base, uint64_t *idx_out,
+                                 float *dist_out, size_t out_stride, hipStream_t s) {
+    return launch_tiny_query<float>(P, n, dim_eff, ldp, Q, ldq, nq, kout, radius_mode, radius, index_base, idx_out, dist_out,
+                                    out_stride, s);
+}
+hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t ldp, const double *Q, size_t ldq, int nq,
+                                 int kout, bool radius_mode, double radius, uint64_t index_base, uint64_t *idx_out,
+                                 double *dist_out, size_t out_stride, hipStream_t s) {
+    return launch_tiny_query<double>(P, n, dim_eff, ldp, Q, ldq, nq, kout, radius_mode, radius, index_base, idx_out,
+                                     dist_out, out_stride, s);
+}
+
+// ---------------------------------------------------------------------------
 // radius: exact check of the filter's survivors.  block = 64 threads = one query.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__restrict__ rcnt,
