@@ -326,15 +326,25 @@ class ShardedBallTree:
             rows = points_fn(self.lo, self.hi) if self.n_local > 0 else None
             if rows is not None and not isinstance(rows, torch.Tensor):
                 rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(f"cuda:{engine.device}")
-            cid = torch.zeros(128, dtype=torch.uint8)
+            # Failure-symmetric: rank 0 may fail to make the id (RCCL not loadable: PN_ERR_COMM) -- it then still takes
+            # part in the broadcast, with a status byte in front of an all-zero id, and EVERY rank raises after it.  (A
+            # rank 0 that raised before the broadcast left the others blocked in it.)
+            cid = torch.zeros(129, dtype=torch.uint8)
+            err = None
             if self.rank == 0:
-                cid = torch.frombuffer(bytearray(ShardedIndex.unique_id()), dtype=torch.uint8).clone()
+                try:
+                    cid[1:] = torch.frombuffer(bytearray(ShardedIndex.unique_id()), dtype=torch.uint8)
+                    cid[0] = 1
+                except Exception as e:  # noqa: BLE001
+                    err = e
             if self.world > 1:
                 on_gpu = dist.get_backend(group) == "nccl"
                 t = cid.to(f"cuda:{engine.device}") if on_gpu else cid
                 dist.broadcast(t, src=0, group=group)
                 cid = t.cpu()
-            engine.build_rank(rows, self.n, self.rank, self.world, bytes(cid.numpy().tobytes()))
+            if int(cid[0]) != 1:
+                raise err if err is not None else RuntimeError("rank 0 could not create the RCCL communicator id")
+            engine.build_rank(rows, self.n, self.rank, self.world, bytes(cid[1:].numpy().tobytes()))
         elif self.n_local > 0:
             self.engine.build(points_fn(self.lo, self.hi), self.lo)
 

@@ -140,3 +140,55 @@ def test_shard_bounds_partition():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) == -(-n // w) or n == 0
+
+
+class _CollectiveDouble:
+    """An engine that owns its exchange (like AbiShardEngine): ShardedBallTree only carries the communicator id."""
+    collective = True
+    device = 0
+
+    def __init__(self):
+        self.built_with = None
+
+    def build_rank(self, rows, n_total, rank, world, comm_id):
+        self.built_with = comm_id
+
+
+def _id_worker(rank, world, port, fail, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from petal_neighbors_amd import sharded
+        good = bytes(range(128))
+
+        def unique_id():
+            if fail:
+                raise RuntimeError("RCCL cannot be loaded")
+            return good
+        sharded.ShardedIndex.unique_id = staticmethod(unique_id)  # (no GPU here: the id's maker is the double)
+        eng = _CollectiveDouble()
+        outcome = "built"
+        try:
+            sharded.ShardedBallTree(100, lambda lo, hi: torch.zeros((hi - lo, 4)), engine=eng)  # (tensors are taken as they are)
+            assert eng.built_with == good
+        except RuntimeError as e:
+            outcome = "raised: " + str(e)
+        with open(os.path.join(out_dir, f"id{rank}.txt"), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_communicator_id_broadcast_is_failure_symmetric(tmp_path, fail):
+    """Rank 0 failing to make the communicator id must not leave the other ranks blocked in the broadcast: it still
+    broadcasts (status byte + zero id) and EVERY rank raises."""
+    port = _free_port()
+    mp.spawn(_id_worker, args=(2, port, fail, str(tmp_path)), nprocs=2, join=True)
+    got = [open(os.path.join(tmp_path, f"id{r}.txt")).read() for r in range(2)]
+    if fail:
+        assert all(g.startswith("raised") for g in got), got
+    else:
+        assert got == ["built", "built"]
