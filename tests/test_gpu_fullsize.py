@@ -214,3 +214,25 @@ def test_c5_shard_query_chunk_loop(pn, oracle_mod):
     n, dim, nq, k = 12_500_000, 96, 300_000, 10
     tree, *_ = _run(pn, oracle_mod, n, dim, nq, k, n_exact=2048, n_oracle=12, max_fallback=nq // 1000)
     _cleanup(tree)
+
+
+@pytest.mark.parametrize("dtype,n,dim", [(np.float32, 16384, 128), (np.float64, 16384, 16), (np.float32, 8192, 768)])
+def test_pairwise_at_the_benched_sizes(pn, oracle_mod, dtype, n, dim):
+    """distance::pairwise at the sizes of the roofline table (DESIGN.md 4.3; tools/bench_pairwise.py): the HBM-resident
+    entry, 33 000 tiles of the upper triangle.  Checked by properties on the whole matrix (symmetric bit for bit, zero
+    diagonal, no NaN) and against the scalar metric (the oracle's bits) on sampled pairs spread over all tile rows."""
+    import torch
+    x = uniform((n, dim), 8800 + dim, dtype)
+    xd = torch.from_numpy(x).to("cuda:0")
+    got = pn.distance.pairwise_device(xd)
+    torch.cuda.synchronize()
+    view = torch.int32 if dtype == np.float32 else torch.int64
+    assert torch.equal(got.view(view), got.t().contiguous().view(view))
+    assert bool((torch.diagonal(got) == 0).all()) and not bool(torch.isnan(got).any())
+    rng = np.random.default_rng(dim)
+    ii = np.concatenate([rng.integers(0, n, 3000), np.arange(0, n, 257), [0, n - 1, n - 1]])
+    jj = np.concatenate([rng.integers(0, n, 3000), np.arange(0, n, 257)[::-1], [n - 1, 0, n - 2]])
+    vals = got[torch.from_numpy(ii).to("cuda:0"), torch.from_numpy(jj).to("cuda:0")].cpu().numpy()
+    for a in range(len(ii)):
+        want = oracle_mod.euclidean(x[ii[a]], x[jj[a]]) if ii[a] != jj[a] else dtype(0)
+        assert vals[a].tobytes() == dtype(want).tobytes(), (ii[a], jj[a])
