@@ -1195,7 +1195,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     if (p.ok && level == 0 && ix->filter_slots == 0 && p.split == 1 && per_tile >= 2 &&
         p.n_wg % (int)q_tiles == 0) {
         const size_t run_len = r_tiles / per_tile;
-        double t = 1.2 * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup for lambda = 1.2
+        double lam_target = 1.2;
+        if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_target = atof(e);  // experiments only
+        double t = lam_target * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup for lambda = 1.2
         if (t > 64.0) t = 64.0;
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
         p.scout_tiles = (int)t;
