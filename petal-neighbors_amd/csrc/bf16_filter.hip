@@ -1294,12 +1294,17 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         char *wd = dst + wave * (P * 1024);
 #ifndef PN_DIAG_BF_NODMA  // NODMA is timing-only: tiles are never loaded
         static_assert(P <= 5, "piece schedule written out for up to five pieces per wave");
+#ifdef PN_DIAG_BF_HALFDMA  // TIMING ONLY (wrong results): half the LDS-DMA instructions -- what an 8-wave workgroup would issue per wave
+        if (0 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 0, 0);
+        if (P > 2 && 2 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 2048, 0);
+#else
         if (0 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 0, 0);
         if (P > 1 && 1 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 1024, 0);
         if (P > 2 && 2 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 2048, 0);
         if (P > 3 && 3 < n_mine) __builtin_amdgcn_global_load_lds((glb_void_b *)ws, (lds_void_b *)wd, 16, 3072, 0);
         if (P > 4 && 4 < n_mine)
             __builtin_amdgcn_global_load_lds((glb_void_b *)(ws + 4096), (lds_void_b *)(wd + 4096), 16, 0, 0);
+#endif
 #endif
     };
 

@@ -338,7 +338,10 @@ def test_shared_thresholds_only_change_the_candidate_count(pn, oracle_mod):
     tree = pn.BallTree.euclidean(pts)
     tree.set_engine("bf16")
     got = {}
-    for mode in (0, 1, 24, 2):  # (r = 2 last: its unproven queries make the index plan conservatively from then on)
+    for mode in (0, 1, 44, 2):
+        if mode == 2:  # a fresh index: a call that leaves > 1/16 of its queries unproven makes an index plan conservatively
+            tree = pn.BallTree.euclidean(pts)  # (sticky), and r = 2 does exactly that -- so does r = 24 for a third of them
+            tree.set_engine("bf16")
         tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, mode)
         tree.stats(reset=True)
         for _ in range(3):  # consecutive calls on one workspace: the epoch of the published words changes every call

@@ -19,6 +19,8 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import uniform
+
 pytestmark = pytest.mark.gpu
 
 SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002
