@@ -1228,7 +1228,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     if (p.shared_scout && p.aligned && ix->shared_tau != 0 && bf16_shared_supported(p.cap)) {
         const int slots = 2 * ix->n_cu - p.n_wg;
         const int rank = ix->shared_tau >= 2 ? ix->shared_tau : (int)std::ceil(R + 5.5 * std::sqrt(R));
-        // (a refresher holds up to 512 keys of a query's union in registers; a refresher pass over the queries takes
+        // (a refresher holds up to 512 keys of a query's union in registers -- and at k = 100 (r = 330, 128-slot buffers)
+        // sharing measured 6 % SLOWER, 3.44 -> 3.65 ms: there a buffer's own compactions already keep its threshold near
+        // the k'-th bound; a refresher pass over the queries takes
         // ~0.25 ms, so short runs end before it pays: a 125 k-row shard of C2, 163 tiles per run, measured 2 % slower)
         if (slots >= 4 && rank <= 256 && rank < p.nseg * p.cap && r_tiles / per_tile >= 512) {
             p.n_refresh = slots > 64 ? 64 : slots;
