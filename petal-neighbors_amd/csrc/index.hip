@@ -1861,8 +1861,9 @@ static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t n
 }
 
 // common tail of the filtered radius paths: kept rows per query (w_keys, ascending) -> CSR on the host
-static int radius_finish(const pn_index *ix, Workspace &ws, const float *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
-                         const uint32_t *d_over, float radius, uint64_t *offsets, uint64_t **idx_out, bool *done,
+template <typename T>
+static int radius_finish(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
+                         const uint32_t *d_over, T radius, uint64_t *offsets, uint64_t **idx_out, bool *done,
                          hipStream_t s) {
     uint32_t h_misc[2] = {0, 0};
     std::vector<uint32_t> h_n(nq);
@@ -1921,15 +1922,15 @@ static int radius_finish(const pn_index *ix, Workspace &ws, const float *Qp, siz
         uint64_t *out_x = nullptr;
         int rc = PN_OK;
         sel.push_back((uint32_t)nf);  // the gather kernel reads its row count from the device: kept behind the list
-        if (ws.w_gsel.ensure((nf + 1) * sizeof(uint32_t)) != PN_OK || ws.w_gq.ensure(nf_pad * ix->ld * sizeof(float)) != PN_OK ||
-            hipMemsetAsync(ws.w_gq.p, 0, nf_pad * ix->ld * sizeof(float), s) != hipSuccess ||
+        if (ws.w_gsel.ensure((nf + 1) * sizeof(uint32_t)) != PN_OK || ws.w_gq.ensure(nf_pad * ix->ld * sizeof(T)) != PN_OK ||
+            hipMemsetAsync(ws.w_gq.p, 0, nf_pad * ix->ld * sizeof(T), s) != hipSuccess ||
             hipMemcpyAsync(ws.w_gsel.p, sel.data(), (nf + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
-            launch_gather_rows_f32(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, (const uint32_t *)ws.w_gsel.p + nf, 0,
-                                   (uint32_t)nf, (float *)ws.w_gq.p, s) != hipSuccess ||
+            launch_gather_rows<T>(Qp, ix->ld, (const uint32_t *)ws.w_gsel.p, (const uint32_t *)ws.w_gsel.p + nf, 0,
+                                  (uint32_t)nf, (T *)ws.w_gq.p, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)  // `sel` is pageable host memory: the copy must have left it
             rc = fail(PN_ERR_DEVICE, "radius fallback staging failed: %s", hipGetErrorString(hipGetLastError()));
         if (rc == PN_OK)
-            rc = radius_exact<float>(ix, ws, (const float *)ws.w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
+            rc = radius_exact<T>(ix, ws, (const T *)ws.w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
         if (rc != PN_OK) {
             free(h_out);
             return rc;
@@ -1975,7 +1976,10 @@ static int radius_finish(const pn_index *ix, Workspace &ws, const float *Qp, siz
 }
 
 // first tier for radius queries: the bf16 filter against each query's fixed bound, exact check of the survivors
-static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float *Qp, size_t nq, size_t nq_pad, float radius, uint64_t *offsets,
+// (f32 and f64 indexes: the filter bounds real squared distances; the survivors' check and the threshold's rounding
+// allowance follow the element type -- u = 2^-24 or 2^-53)
+template <typename T>
+static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const T *Qp, size_t nq, size_t nq_pad, T radius, uint64_t *offsets,
                        uint64_t **idx_out, bool *done, hipStream_t s) {
     *done = false;
     const int cap = 256;  // up to 224 rows within the radius per (segment, query) before the call overflows
@@ -1998,7 +2002,10 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
     const size_t kept_stride = (size_t)nseg * cap;
     // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24): every row whose reference distance is < r has a squared distance
     // below it (same allowances as the k-NN proof)
-    const double t = ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08);
+    const double t = sizeof(T) == 4
+                         ? ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08)
+                         : ((double)radius * (double)radius * (1.0 + 8.881784197001252e-16) + 1e-300) /
+                               (1.0 - (double)(ix->dim + 4) * 1.1102230246251565e-16);  // (f64: r^2 itself is rounded)
     if (!(t < 1e37)) return PN_OK;  // let the exact engine decide
     PNCHK(ws.w_bq.ensure(bf16_query_bytes(nq_pad, (int)ix->dim, ix->bf16_ci)));
     PNCHK(ws.w_qn.ensure(nq_pad * sizeof(double)));
@@ -2037,12 +2044,12 @@ static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const float
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, cap - 32, cb, (int)n_wg, 1, 0,
                                   (const uint32_t *)ws.w_seed.p, true, nullptr, ix->bf16_ci, s));
     if (prof) HIPCHK(hipEventRecord(ws.ev_r[1], s));
-    HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
-                                   (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
-                                   (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
-                                   (uint32_t *)ws.w_sel.p, s));
-    const int rc = radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets, idx_out,
-                                 done, s);
+    HIPCHK(launch_radius_check<T>((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
+                                  (const T *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
+                                  (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
+                                  (uint32_t *)ws.w_sel.p, s));
+    const int rc = radius_finish<T>(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets,
+                                    idx_out, done, s);
     if (prof && rc == PN_OK) {  // (radius_finish has waited for the stream)
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ws.ev_r[0], ws.ev_r[1]) == hipSuccess) {
@@ -2091,7 +2098,7 @@ static int radius_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_
     HIPCHK(launch_radius_check_f32((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p, nq_pad, nseg, cap,
                                    (const float *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                    (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 1, nullptr, s));
-    return radius_finish(ix, ws, Qp, nq, kept_stride, d_misc, nullptr, radius, offsets, idx_out, done, s);
+    return radius_finish<float>(ix, ws, Qp, nq, kept_stride, d_misc, nullptr, radius, offsets, idx_out, done, s);
 }
 
 template <typename T>
@@ -2131,14 +2138,14 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
             rc = fail(PN_ERR_DEVICE, "pack failed");
             break;
         }
+        const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
+        if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
+            (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
+            bool done = false;  // (f32 and f64 indexes)
+            rc = radius_bf16<T>(ix, ws, level, (const T *)Qp, nq, nq_pad, radius, offsets, idx_out, &done, s);
+            if (rc != PN_OK || done) break;
+        }
         if constexpr (sizeof(T) == 4) {
-            const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-            if (ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
-                (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
-                bool done = false;
-                rc = radius_bf16(ix, ws, level, (const float *)Qp, nq, nq_pad, (float)radius, offsets, idx_out, &done, s);
-                if (rc != PN_OK || done) break;
-            }
             if (ix->mfma_ok && ix->ld <= 128 && dim_eff == ix->dim && ix->engine != PN_ENGINE_EXACT && finite_pos &&
                 (ix->engine == PN_ENGINE_MFMA || (ix->n >= 4096 && ix->dim >= 8))) {
                 bool done = false;

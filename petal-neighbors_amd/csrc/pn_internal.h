@@ -156,6 +156,13 @@ hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_pa
                                  const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
 // gather rows sel[off + i] of src into dst row i / scatter result rows i back to query sel[off + i], for
 // i < min(max_rows, *nsel - off): the count stays on the device
+template <typename T>  // T = float | double (explicitly instantiated)
+hipError_t launch_gather_rows(const T *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
+                              uint32_t max_rows, T *dst, hipStream_t s);
+template <typename T>
+hipError_t launch_radius_check(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
+                               const T *P, size_t ldp, const T *Q, int nq, int dim, T r, uint32_t *kept,
+                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s);
 hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
                                   uint32_t max_rows, float *dst, hipStream_t s);
 hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel,

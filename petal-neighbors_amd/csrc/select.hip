@@ -821,10 +821,11 @@ hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t 
 // ---------------------------------------------------------------------------
 // radius: exact check of the filter's survivors.  block = 64 threads = one query.
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__restrict__ rcnt,
                                                           const uint32_t *__restrict__ ridx, size_t nq_pad, int nseg,
-                                                          uint32_t cap, const float *__restrict__ P, size_t ldp,
-                                                          const float *__restrict__ Q, int dim, float r,
+                                                          uint32_t cap, const T *__restrict__ P, size_t ldp,
+                                                          const T *__restrict__ Q, int dim, T r,
                                                           uint32_t *__restrict__ kept, uint32_t *__restrict__ nkept,
                                                           uint32_t *__restrict__ overflow, int ridx_stride,
                                                           uint32_t *__restrict__ over_q) {
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
     const size_t q = blockIdx.x;
     if (lane == 0) n_pass = 0;
     __syncthreads();
-    const float *qrow = Q + q * ldp;
+    const T *qrow = Q + q * ldp;
     bool over = false;
     for (int s = 0; s < nseg; ++s) {
         uint32_t c = rcnt[(size_t)s * nq_pad + q];
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
         const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
         for (uint32_t e = lane; e < c; e += 64) {
             const uint32_t row = ridx[(base + e) * (size_t)ridx_stride];
-            const float d = exact_distance_f32(qrow, P + (size_t)row * ldp, dim);
+            const T d = exact_distance_seq<T>(qrow, P + (size_t)row * ldp, dim);
             if (d < r) srow[atomicAdd(&n_pass, 1u)] = row;  // strict '<' (src/ball_tree.rs:277); NaN never matches
         }
     }
@@ -863,15 +864,28 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
     }
 }
 
+template <typename T>
+hipError_t launch_radius_check(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
+                               const T *P, size_t ldp, const T *Q, int nq, int dim, T r, uint32_t *kept,
+                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s) {
+    const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(radius_check_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp,
+                       Q, dim, r, kept, nkept, overflow, ridx_stride, over_q);
+    return hipGetLastError();
+}
+template hipError_t launch_radius_check<float>(const uint32_t *, const uint32_t *, size_t, int, uint32_t, const float *, size_t,
+                                               const float *, int, int, float, uint32_t *, uint32_t *, uint32_t *, int,
+                                               uint32_t *, hipStream_t);
+template hipError_t launch_radius_check<double>(const uint32_t *, const uint32_t *, size_t, int, uint32_t, const double *,
+                                                size_t, const double *, int, int, double, uint32_t *, uint32_t *, uint32_t *,
+                                                int, uint32_t *, hipStream_t);
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
                                    uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride,
                                    uint32_t *over_q, hipStream_t s) {
-    const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
-    if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q,
-                       dim, r, kept, nkept, overflow, ridx_stride, over_q);
-    return hipGetLastError();
+    return launch_radius_check<float>(rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q, nq, dim, r, kept, nkept, overflow,
+                                      ridx_stride, over_q, s);
 }
 
 __global__ void radius_gather_kernel(const uint32_t *__restrict__ kept, const uint32_t *__restrict__ nkept,
@@ -1038,24 +1052,34 @@ hipError_t launch_compact_flags(const uint32_t *flags, int nq, uint32_t *sel, ui
     return hipGetLastError();
 }
 
-__global__ void gather_rows_kernel(const float *__restrict__ src, size_t ld, const uint32_t *__restrict__ sel,
+template <typename T>
+__global__ void gather_rows_kernel(const T *__restrict__ src, size_t ld, const uint32_t *__restrict__ sel,
                                    const uint32_t *__restrict__ nsel, uint32_t off, uint32_t max_rows,
-                                   float *__restrict__ dst) {
+                                   T *__restrict__ dst) {
     const uint32_t tot = *nsel;
     uint32_t cnt = tot > off ? tot - off : 0u;
     if (cnt > max_rows) cnt = max_rows;
     for (size_t i = blockIdx.x; i < (size_t)cnt; i += gridDim.x) {
-        const float *s = src + (size_t)sel[off + i] * ld;
-        float *d = dst + i * ld;
+        const T *s = src + (size_t)sel[off + i] * ld;
+        T *d = dst + i * ld;
         for (size_t c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
     }
 }
-hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
-                                  uint32_t max_rows, float *dst, hipStream_t s) {
+template <typename T>
+hipError_t launch_gather_rows(const T *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
+                              uint32_t max_rows, T *dst, hipStream_t s) {
     if (max_rows == 0) return hipSuccess;
     const unsigned grid = max_rows < 1024u ? max_rows : 1024u;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(64), 0, s, src, ld, sel, nsel, off, max_rows, dst);
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(grid), dim3(64), 0, s, src, ld, sel, nsel, off, max_rows, dst);
     return hipGetLastError();
+}
+template hipError_t launch_gather_rows<float>(const float *, size_t, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
+                                              float *, hipStream_t);
+template hipError_t launch_gather_rows<double>(const double *, size_t, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
+                                               double *, hipStream_t);
+hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
+                                  uint32_t max_rows, float *dst, hipStream_t s) {
+    return launch_gather_rows<float>(src, ld, sel, nsel, off, max_rows, dst, s);
 }
 
 __global__ void scatter_results_kernel(const uint64_t *__restrict__ idx_in, const float *__restrict__ dist_in,

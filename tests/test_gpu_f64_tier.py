@@ -86,3 +86,22 @@ def test_f64_device_entry_point(pn, oracle_mod):
     ei, ed = tree.query_device(qd, k)
     torch.cuda.synchronize()
     assert torch.equal(di, ei) and torch.equal(dd.view(torch.int64), ed.view(torch.int64))
+
+
+@pytest.mark.parametrize("n,dim,nq", [(30000, 64, 150), (12000, 128, 90), (9000, 300, 40)])
+def test_f64_query_radius_through_the_bf16_tier(pn, oracle_mod, n, dim, nq):
+    """BallTree::query_radius on an f64 index: the bf16 filter against each query's fixed bound (threshold rounded with
+    u = 2^-53), the survivors checked in the reference's f64 fold with the strict '<' of src/ball_tree.rs:277."""
+    pts, qs = _f64((n, dim), 81 + n), _f64((nq, dim), 82 + n)
+    qs[:2] = pts[:2]
+    tree = pn.BallTree.euclidean(pts)
+    _, d = oracle_mod.brute_knn(pts, qs, 4)
+    radii = [float(np.median(d[:, -1])), float(d[:, 1].max()) * 1.0000001, float(d[5, 2])]  # incl. a radius EQUAL to a distance
+    for eng in ("bf16", "auto", "exact"):
+        tree.set_engine(eng)
+        for r in radii:
+            off, ids = tree.query_radius_batch(qs, r)
+            assert off[0] == 0 and off[-1] == len(ids)
+            for a in range(nq):
+                want = oracle_mod.brute_radius(pts, qs[a], np.float64(r))
+                assert np.array_equal(ids[int(off[a]):int(off[a + 1])], want), (eng, r, a)
