@@ -167,7 +167,14 @@ int pn_index_get_stats(const pn_index *index, pn_stats *out, int reset);
  * (src/distance.rs:27-28) the distance runs over min(q_cols, dim) coordinates.
  * Writes nq rows of kout = min(k, n_points) results, ascending by distance;
  * k = 0 writes nothing and succeeds (src/ball_tree.rs:106-108).  Never fails on
- * NaN coordinates (CHANGELOG.md:113-115). */
+ * NaN coordinates (CHANGELOG.md:113-115).
+ * One point per call is a supported pattern: corpora of at most 4096 rows answer a call of <= 64 queries with one
+ * kernel launch (query and answer through mapped pinned memory); a handful of queries against a large corpus are spread
+ * over every CU.  f64 indexes take the same first tier as f32 ones (bf16 filter, then f64 re-rank and proof).
+ * Scratch: every call works in a pooled per-handle workspace that grows to the largest call seen -- for a filter-tier
+ * batch of 10^4 queries ~0.4 GB (candidate buffers + the second tier's worst case), allocated on the first such call
+ * (hipMalloc: no device-wide wait); a buffer that has to grow is retired behind the workspace's end-of-use event, never
+ * freed inside a call.  Each concurrent host thread (and each shard sharing a GPU) has its own workspace. */
 int pn_query_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
                  ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out);
 int pn_query_f64(const pn_index *index, const double *queries, size_t nq, size_t q_cols,
