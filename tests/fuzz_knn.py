@@ -14,13 +14,14 @@ from conftest import uniform  # noqa: E402
 
 
 def run_case(c, rng):
-    n = int(rng.choice([4096, 5000, 9000, 20000, 33000, 60000]))
-    dim = int(rng.choice([8, 15, 16, 31, 64, 96, 100, 128, 129, 200, 384, 768, 1024]))
+    n = int(rng.choice([64, 1000, 3000, 4096, 5000, 9000, 20000, 33000, 60000]))  # (<= 4096 with few queries: one-launch path)
+    dim = int(rng.choice([3, 8, 15, 16, 31, 64, 96, 100, 128, 129, 200, 384, 768, 1024]))
     nq = int(rng.choice([1, 7, 64, 255, 256, 257, 600, 1300]))
     if dim > 128:  # wide rows (K-chunked bf16 kernel): keep the oracle's brute force to seconds
         n, nq = min(n, 20000), min(nq, 600)
     k = int(rng.choice([1, 2, 5, 10, 33, 100]))
     kind = rng.choice(["uniform", "centered", "clustered", "dups", "sorted"])
+    f64 = bool(rng.integers(0, 3) == 0)  # a third of the cases: an f64 index (bf16 filter, f64 re-rank and second tier)
     pts = uniform((n, dim), 1000 + c)
     if kind == "centered":
         pts = pts - np.float32(0.5)
@@ -33,20 +34,26 @@ def run_case(c, rng):
         pts = pts[np.argsort(pts[:, 0])]
     qs = pts[rng.integers(0, n, nq)] + np.float32(0.01) * (uniform((nq, dim), 5000 + c) - np.float32(0.5)) if kind != "uniform" else uniform((nq, dim), 5000 + c)
     qs = np.ascontiguousarray(qs, dtype=np.float32)
+    if f64:  # coordinates with more than 24 significant bits
+        pts = pts.astype(np.float64) + uniform((n, dim), 31000 + c).astype(np.float64) * 2.0 ** -26
+        if kind == "dups":
+            pts[n // 2:] = pts[: n - n // 2]
+        qs = qs.astype(np.float64) + uniform((nq, dim), 32000 + c).astype(np.float64) * 2.0 ** -26
     t = pn.BallTree.euclidean(pts)
     idx, dist = t.query_batch(qs, k)
     oi, od = oracle.brute_knn(pts, qs, k)
     ok = dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)
     # radius queries through the same tiers: a radius just above / exactly at a stored distance (strict '<')
     nr = min(nq, 8)
-    for r in (np.float32(od[0, int(rng.integers(0, od.shape[1]))]) * np.float32(1.000001), np.float32(od[0, -1])):
+    ft = np.float64 if f64 else np.float32
+    for r in (ft(od[0, int(rng.integers(0, od.shape[1]))]) * ft(1.000001), ft(od[0, -1])):
         if not np.isfinite(r) or r <= 0:
             continue
         off, ids = t.query_radius_batch(qs[:nr], float(r))
         for a in range(nr):
             ok = ok and np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle.brute_radius(pts, qs[a], r))
     st = t.stats()
-    print(f"case {c}: n={n} D={dim} nq={nq} k={k} {kind}: {'ok' if ok else 'MISMATCH'} fallback {st['fallback_queries']}/{st['queries']} cand/q {st['candidates']/max(st['queries'],1):.0f}", flush=True)
+    print(f"case {c}: n={n} D={dim} nq={nq} k={k} {kind}{' f64' if f64 else ''}: {'ok' if ok else 'MISMATCH'} fallback {st['fallback_queries']}/{st['queries']} cand/q {st['candidates']/max(st['queries'],1):.0f}", flush=True)
     return ok
 
 
