@@ -254,6 +254,50 @@ static int check_device(int device) {
     return PN_OK;
 }
 
+// hipStreamCreate / hipStreamDestroy cost 0.4-1 ms each on this runtime (hip-trace, round 3: they were 90 % of a
+// 128 x 10 index build), so the library's own streams are recycled through a small per-process pool.  A stream carries
+// no state but its ordering, and one is only returned here once everything enqueued on it has completed.  The pool is
+// never destroyed (the runtime may already be shutting down when static destructors run).
+namespace {
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool() {
+    static StreamPool *p = new StreamPool();
+    return *p;
+}
+constexpr size_t kStreamPoolMax = 32;
+}  // namespace
+static hipStream_t pooled_stream_acquire(int device) {   // the caller has made `device` current
+    {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].first == device) {
+                hipStream_t s = p.idle[i].second;
+                p.idle[i] = p.idle.back();
+                p.idle.pop_back();
+                return s;
+            }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+static void pooled_stream_release(int device, hipStream_t s) {   // `s` is idle
+    if (!s) return;
+    {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        if (p.idle.size() < kStreamPoolMax) {
+            p.idle.emplace_back(device, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 static size_t pick_ld(size_t dim) {
     // D <= 128: one of the row lengths the MFMA filter is instantiated for; else a multiple of 8
     const size_t set[] = {8, 16, 32, 64, 96, 128};
@@ -421,7 +465,7 @@ static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdi
     int rc = PN_OK;
     T *d_tmp = nullptr;
     do {
-        if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (!(ix->stream = pooled_stream_acquire(device))) {
             rc = fail(PN_ERR_DEVICE, "hipStreamCreate failed");
             break;
         }
@@ -442,6 +486,10 @@ static int create_from_host(const T *points, size_t n_rows, size_t n_cols, ptrdi
         }
         rc = finish_index<T>(ix, d_tmp, n_cols, ix->stream);
     } while (0);
+    if (rc == PN_OK) {   // finish_index ends with the stream drained: the build stream goes back to the pool
+        pooled_stream_release(device, ix->stream);
+        ix->stream = nullptr;
+    }
     if (d_tmp) (void)hipFree(d_tmp);
     if (rc != PN_OK) {
         pn_index_destroy(ix);
@@ -486,14 +534,17 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
     ix->ld = pick_ld(n_cols);
     ix->n_pad = round_up(n_rows, kRowPad);
     int rc = PN_OK;
-    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess)
-        rc = fail(PN_ERR_DEVICE, "hipStreamCreate failed");
+    if (!(ix->stream = pooled_stream_acquire(device))) rc = fail(PN_ERR_DEVICE, "hipStreamCreate failed");
     if (rc == PN_OK) {
         // order after the producer of d_points on `stream`
         hipStream_t src = (hipStream_t)stream;
         if (hipStreamSynchronize(src) != hipSuccess) rc = fail(PN_ERR_DEVICE, "stream sync failed");
     }
     if (rc == PN_OK) rc = finish_index<float>(ix, d_points, row_stride, ix->stream);
+    if (rc == PN_OK) {
+        pooled_stream_release(device, ix->stream);
+        ix->stream = nullptr;
+    }
     if (rc != PN_OK) {
         pn_index_destroy(ix);
         return rc;
@@ -516,7 +567,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
         if (ws->pin_in) (void)hipHostFree(ws->pin_in);
         if (ws->pin_out) (void)hipHostFree(ws->pin_out);
         if (ws->done) (void)hipEventDestroy(ws->done);
-        if (ws->stream) (void)hipStreamDestroy(ws->stream);
+        pooled_stream_release(ix->device, ws->stream);
         delete ws;
     }
     for (CallRec &r : ix->sh.recs) {
@@ -531,7 +582,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_norm) (void)hipFree(ix->d_norm);
     if (ix->d_cnorm) (void)hipFree(ix->d_cnorm);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
-    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    pooled_stream_release(ix->device, ix->stream);
     if (HostTree *t = ix->sh.tree.load()) host_tree_free(t);
     delete ix;
 }
@@ -553,16 +604,22 @@ static int ws_acquire(const pn_index *ix, hipStream_t *s, bool own_stream, Works
     if (!ws) {
         ws = new (std::nothrow) Workspace();
         if (!ws) return fail(PN_ERR_NOMEM, "host allocation failed");
-        if (hipEventCreateWithFlags(&ws->done, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess) {
-            if (ws->done) (void)hipEventDestroy(ws->done);
+        if (hipEventCreateWithFlags(&ws->done, hipEventDisableTiming) != hipSuccess) {
             delete ws;
             return fail(PN_ERR_DEVICE, "workspace creation failed: %s", hipGetErrorString(hipGetLastError()));
         }
         std::lock_guard<std::mutex> lk(ix->sh.mu);
         ix->sh.all_ws.push_back(ws);
     }
-    if (own_stream) *s = ws->stream;
+    if (own_stream) {
+        // only the host entry points run on a stream of the library's own; calls on a caller's stream never need one
+        if (!ws->stream && !(ws->stream = pooled_stream_acquire(ix->device))) {
+            std::lock_guard<std::mutex> lk(ix->sh.mu);
+            ix->sh.free_ws.push_back(ws);
+            return fail(PN_ERR_DEVICE, "workspace stream creation failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        *s = ws->stream;
+    }
     // allocations outgrown by an earlier call: free them once everything that call enqueued has finished
     if (!ws->retired.empty() && (!ws->in_flight || hipEventQuery(ws->done) == hipSuccess)) ws->free_retired();
     if (ws->in_flight && ws->last_stream != *s) {
