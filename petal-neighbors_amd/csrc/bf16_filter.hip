@@ -585,6 +585,10 @@ constexpr int kBfTagFromM = 2;
 #else
 constexpr int kBfTagFromM = 1000;
 #endif
+#ifndef PN_DIAG_BF_FINALKEEP
+#define PN_DIAG_BF_FINALKEEP 32
+#endif
+constexpr int kBfFinalKeep = PN_DIAG_BF_FINALKEEP;  // 64-slot buffers holding at most this many entries end a run uncut
 constexpr int kScoutList = 12;  // smallest block minima a lane keeps during a scout pass
 // smallest (mn) and second smallest (sec) of 16 finite values: triples give (min3, med3); the second smallest overall
 // is the smaller of {second smallest of the triples' minima, the smallest of the triples' medians} -- 21 instructions.
@@ -1215,7 +1219,7 @@ struct BfShared {
 template <int KS, int M, bool RAD, bool CI, int MODE, bool CAPT, bool SH = false>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
-                                                             uint32_t kp, uint2 *__restrict__ cand,
+                                                             uint32_t kp_keep, uint2 *__restrict__ cand,
                                                              uint32_t *__restrict__ ccnt,
                                                              uint32_t *__restrict__ ctau, size_t nq_pad,
                                                              uint32_t split, uint32_t seg_per_part,
@@ -1223,6 +1227,8 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                                                              const uint32_t *tau_init,
                                                              float *__restrict__ scout_out, BfShared sh) {
     static_assert(!SH || (MODE == 2 && !RAD && !CAPT), "shared thresholds: main pass of a k-NN call only");
+    // k' in the low half; the high half: entries up to which a buffer ends its run uncut (0: k'; see the end of a run)
+    const uint32_t kp = kp_keep & 0xFFFFu, keep_arg = kp_keep >> 16;
     constexpr int C = 2 * KS, CP = C + 1;
     constexpr uint32_t CAP = 64u * M;
     constexpr bool TAG = M >= kBfTagFromM;
@@ -1787,21 +1793,27 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
             const unsigned long long te0_ = bf_stamp();
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // Every buffer is cut to its k' smallest bounds here.  Measured alternative (-DPN_DIAG_BF_FINALCOMPACT_FROM=2:
-            // 64-slot buffers handed over as they are -- valid, the proof only gets a looser threshold): the kernel
-            // loses its serial tail (C2 -3 %, a 125 k-row shard of C2 -14 %) and the re-rank gains 50 % more candidates
-            // to gather; the step as a whole came out 1 % slower, so the cut stays.
+            // A buffer is cut to its k' smallest bounds here only when it holds more than kfin entries.  Handing a
+            // buffer over as it is is always valid (the proof only gets a looser threshold); what it costs is re-rank
+            // LDS, which is sized for what a cell can hold.  Measured (round 3, one device, a 125 k-row shard of C2 /
+            // C2): every buffer cut to k' = 13: kernel 0.530 / 2.34 ms, step 0.644 / 2.48; none cut
+            // (-DPN_DIAG_BF_FINALCOMPACT_FROM=2; cells of up to 64 entries): kernel 0.467 / 2.34, step 0.659 / 2.50 --
+            // the serial tail of up to 128 compactions per wave (16 % of a shard's run) is gone but the re-rank's waves
+            // per CU halve with 9 KB of LDS each.  So the host names the count up to which a buffer stays uncut
+            // (bf16_cell_max: 32 of 64 slots while the re-rank's LDS stays near 5 KB; a buffer holds 18 entries on
+            // average at the end of a run): DESIGN.md 4.0.
 #ifdef PN_DIAG_BF_FINALCOMPACT_FROM
             constexpr bool kFinalCompact = M >= (PN_DIAG_BF_FINALCOMPACT_FROM);
 #else
             constexpr bool kFinalCompact = true;
 #endif
+            const uint32_t kfin = keep_arg > kp ? keep_arg : kp;
             // 64-slot buffers four at a time: their entries are requested together, then selected one after the other
             // (a buffer at a time pays a memory round trip per buffer: up to 128 in a row at the end of every run;
             // larger buffers stay one at a time -- four of them in registers made the kernel spill)
             constexpr int NB = M == 1 ? 4 : 1;
             auto final_compact = [&](uint2 *ce_blk, float &tau, uint32_t &cnt) {
-                unsigned long long need = RAD || !kFinalCompact ? 0ull : __ballot(h == 0 && cnt > kp);
+                unsigned long long need = RAD || !kFinalCompact ? 0ull : __ballot(h == 0 && cnt > kfin);
                 while (need) {
                     int jj[NB];
                     uint32_t cj[NB], key[NB][M], ixs[NB][M];
@@ -2245,11 +2257,18 @@ int bf16_cap_for(int kp) { return kp <= 16 ? 64 : kp <= 64 ? 128 : 256; }
 #endif
 int bf16_query_tile() { return kBQ; }
 // entries a (segment, query) cell holds at most when a k-NN launch has finished: every run ends with a cut to k'
-int bf16_cell_max(int kp, int cap) {
+int bf16_cell_max(int kp, int cap, int nseg, bool wide) {
 #ifdef PN_DIAG_BF_FINALCOMPACT_FROM
     return cap;
 #else
-    return kp < cap ? kp : cap;
+    const int cut = kp < cap ? kp : cap;
+    if (wide || cap != 64 || nseg < 1) return cut;
+    // 64-slot buffers of the narrow kernel end a run uncut up to `keep` entries (CandBuf::final_keep; the kernel's end of
+    // run has the measurements): as many as keep the re-rank's LDS -- 12 bytes per slot a query's cells can hold -- near
+    // 4.6 KB, i.e. 32 of its one-wave workgroups on a CU
+    int keep = 384 / nseg;
+    if (keep > kBfFinalKeep) keep = kBfFinalKeep;
+    return keep > cut ? keep : cut;
 #endif
 }
 
@@ -2345,6 +2364,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, const Bf16Shared *shp, hipStream_t s) {
     const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16 + 16;  // three tile buffers (software-pipelined main loop) + the arrival counter
+    const uint32_t kp_keep = kp | ((uint32_t)(M == 1 && !RAD && cb.final_keep > (int)kp ? cb.final_keep : 0) << 16);
 #define PN_BF_LAUNCH_MODE(MD)                                                                                          \
     {                                                                                                                   \
         auto kern = bf16_filter_kernel<KS, M, RAD, CI, MD, kBfCapture && (M > 1) && !RAD>;                                                             \
@@ -2352,7 +2372,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);                                 \
         if (e != hipSuccess) return e;                                                                                  \
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,       \
-                           static_cast<const u32x4 *>(B), q_tiles, kp, static_cast<uint2 *>(cb.keys), cb.cnt,           \
+                           static_cast<const u32x4 *>(B), q_tiles, kp_keep, static_cast<uint2 *>(cb.keys), cb.cnt,      \
                            static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out,      \
                            BfShared{});                                                                                 \
     }
@@ -2365,7 +2385,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
             if (e != hipSuccess) return e;
             const BfShared a{shp->pcnt, shp->done, (uint32_t)n_wg, shp->epoch, shp->rank, (uint32_t)cb.nseg};
             hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg + shp->n_refresh)), dim3(256), sh, s,
-                               static_cast<const char *>(img), n_tiles, static_cast<const u32x4 *>(B), q_tiles, kp,
+                               static_cast<const char *>(img), n_tiles, static_cast<const u32x4 *>(B), q_tiles, kp_keep,
                                static_cast<uint2 *>(cb.keys), cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad, split,
                                spp, scout_max, tau_init, scout_out, a);
             return hipGetLastError();

@@ -1397,6 +1397,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
         HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
                                         (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_keys.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
+    cb.final_keep = bf16_cell_max((int)kp, cap, nseg, bf16_is_wide((int)ix->dim));  // what the re-rank sizes its LDS for
     if (!plan.aligned) {  // cells without a writer must read "empty" (an aligned partition writes every cell)
         HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_tau.p, (int)0xFF800000u, cells, s));
@@ -1452,7 +1453,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     HIPCHK(Ops<T>::rerank(cb, (const T *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld, (int)kout,
                           ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p, d_misc,
                           (const double *)ws.w_qn.p, (const uint32_t *)ws.w_qbad.p, (uint32_t *)ws.w_gsel.p, ix->d_stats, s,
-                          plan.first_eval, bf16_cell_max((int)kp, cap)));
+                          plan.first_eval, cb.final_keep));
     return PN_OK;
 }
 
@@ -1509,7 +1510,7 @@ static int query_enqueue(const pn_index *ix, Workspace &ws, const T *d_q, size_t
             bplan = bf16_plan(ix, nq_pad, kout, level);
             use_bf16 = bplan.ok;
             // the re-rank's LDS: (8 or 12) bytes per candidate slot + the query row
-            if (use_bf16 && (size_t)bplan.nseg * (size_t)bf16_cell_max(bplan.kp, bplan.cap) * (sizeof(T) + 8) +
+            if (use_bf16 && (size_t)bplan.nseg * (size_t)bf16_cell_max(bplan.kp, bplan.cap, bplan.nseg, bf16_is_wide((int)ix->dim)) * (sizeof(T) + 8) +
                                     (ix->dim + 8) * sizeof(T) > 64 * 1024)
                 use_bf16 = false;
         }

@@ -60,6 +60,7 @@ struct CandBuf {
     int nseg;
     int cap;         // slots per (segment, query); multiple of 64
     int idx_stride = 1;  // 2: keys and idx interleaved as (key, row) pairs, idx = keys + 1 (bf16 filter)
+    int final_keep = 0;  // bf16 filter, 64-slot buffers: a buffer holding at most this many entries ends its run uncut (0: k')
 };
 
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
@@ -276,7 +277,7 @@ hipError_t launch_bf16_wide_filter(const void *img, size_t n, int dim, const voi
                                    int n_wg, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
                                    hipStream_t s);
 int bf16_scout_list();
-int bf16_cell_max(int kp, int cap);  // entries a cell holds at most after a k-NN launch (its final cut to k')
+int bf16_cell_max(int kp, int cap, int nseg, bool wide);  // entries a cell holds at most after a k-NN launch = CandBuf::final_keep to launch with
 // out[q] = key just above the rank-th smallest value over the lists of q's nseg cells
 // nq (0: nq_pad): the queries beyond it are padding and get the threshold -inf
 hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int rank, uint32_t *out, hipStream_t s,

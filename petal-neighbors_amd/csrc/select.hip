@@ -43,12 +43,14 @@ __device__ __forceinline__ uint32_t rank_of(const KeyT *skey, const IdxT *sidx, 
 // in their original relative order, so that rank_of runs over kout entries instead of n: a radix select on the
 // key (one ballot per 64 entries per bit), then on the index among the keys equal to the kout-th one.  One wave.
 __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane);
+template <typename KeyT>
+__device__ __forceinline__ KeyT kth_smallest_keys(const KeyT *a, uint32_t n, uint32_t k, int lane);
 template <typename KeyT, typename IdxT>
 __device__ __forceinline__ uint32_t prune_to_topk(KeyT *skey, IdxT *sidx, uint32_t n, uint32_t kout, int lane) {
     if (n <= kout || n <= 128) return n;
     KeyT T = 0;  // becomes the kout-th smallest key
-    if (sizeof(KeyT) == 4 && n <= 256u)
-        T = (KeyT)kth_smallest_lds(reinterpret_cast<const uint32_t *>(skey), n, kout, lane);  // words in registers
+    if (n <= 512u)
+        T = kth_smallest_keys<KeyT>(skey, n, kout, lane);  // keys in registers
     else
     for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
         const KeyT cand = T | ((KeyT)1 << b);
@@ -275,30 +277,34 @@ __device__ __forceinline__ float exact_distance_prefetched_f32(const float *qs, 
     return sqrtf(s);
 }
 
-// k-th smallest (1-based) of n LDS words, one wave, array left untouched: radix select, one ballot per 64 words
-// per bit.  Requires 1 <= k <= n.
+// k-th smallest (1-based) of n LDS keys, one wave, array left untouched: radix select.  Requires 1 <= k <= n.
+// W keys per lane held in registers: one round per bit of compare + ballot + scalar popcount, no LDS round trip in them
+// (a round over LDS is latency-bound: ~100 cycles per 64 keys and bit; the re-rank of the headline batch runs three such
+// selections over ~150 candidates per query, a 125 k-row shard's over ~220 with a tail beyond 256)
+template <typename KeyT, int W>
+__device__ __forceinline__ KeyT kth_smallest_regs(const KeyT *a, uint32_t n, uint32_t k, int lane) {
+    KeyT v[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
+        v[i] = e < n ? a[e] : ~(KeyT)0;  // padding: never below a candidate threshold
+    }
+    KeyT T = 0;
+    for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
+        const KeyT cand = T | ((KeyT)1 << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) c += (uint32_t)__popcll(__ballot(v[i] < cand));
+        if (c < k) T = cand;
+    }
+    return T;
+}
+// ... of n LDS words: in registers up to 512 of them, else one ballot per 64 words and bit over LDS
 __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane) {
     uint32_t T = 0;
 #ifndef PN_DIAG_SELECT_LDS
-    if (n <= 256u) {
-        // up to four words per lane, held in registers: 32 rounds of compare + ballot + scalar popcount with no LDS
-        // round trip in them (a round over LDS is latency-bound: ~100 cycles per 64 words and bit; the re-rank of the
-        // headline batch runs three such selections over ~150 candidates per query)
-        uint32_t v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
-            v[i] = e < n ? a[e] : 0xFFFFFFFFu;  // padding: never below a candidate threshold
-        }
-        for (int b = 31; b >= 0; --b) {
-            const uint32_t cand = T | (1u << b);
-            uint32_t c = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c += (uint32_t)__popcll(__ballot(v[i] < cand));
-            if (c < k) T = cand;
-        }
-        return T;
-    }
+    if (n <= 256u) return kth_smallest_regs<uint32_t, 4>(a, n, k, lane);
+    if (n <= 512u) return kth_smallest_regs<uint32_t, 8>(a, n, k, lane);
 #endif
     for (int b = 31; b >= 0; --b) {
         const uint32_t cand = T | (1u << b);
@@ -359,6 +365,8 @@ __device__ __forceinline__ KeyT kth_smallest_keys(const KeyT *a, uint32_t n, uin
     if constexpr (sizeof(KeyT) == 4) {
         return (KeyT)kth_smallest_lds(reinterpret_cast<const uint32_t *>(a), n, k, lane);
     } else {
+        if (n <= 256u) return kth_smallest_regs<KeyT, 4>(a, n, k, lane);
+        if (n <= 512u) return kth_smallest_regs<KeyT, 8>(a, n, k, lane);
         KeyT Tk = 0;
         for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
             const KeyT cand = Tk | ((KeyT)1 << b);
@@ -434,6 +442,7 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ KeyT kth_key;
     __shared__ uint32_t seg_off[65], seg_cnt[64];
+    __shared__ uint32_t elist[64];  // slots of the candidates one evaluation round takes, a lane each
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
 #ifdef PN_DIAG_RR_STAMP
@@ -556,16 +565,43 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         uint32_t K1 = 0xFFFFFFFFu;
         if (!all) K1 = kth_smallest_lds(sfk, n, m1, lane);
         RR_STAMP(2);  // k-th smallest bound
-        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-            const uint32_t e = e0 + lane;
-            const bool go = e < n && (all || sfk[e] <= K1);
-            if (go) {
-                const uint32_t ix = sidx[e];
-                if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
+        // The entries to evaluate are scattered over the n slots (24 of ~150 on the headline batch): evaluated where
+        // they lie, every 64-slot chunk that holds one costs a whole round -- dependent row fetches and the D-step
+        // chain -- for a handful of busy lanes.  So their positions are first packed into lists of 64 (ballot + prefix
+        // count per chunk, no memory traffic), and a list is evaluated with one candidate per lane: one round for the
+        // headline batch's first evaluation instead of three.  `pred` must not depend on what the evaluation writes.
+        auto eval_packed = [&](auto pred) {
+            // (up to 64 chunks: a lane remembers its slots' verdicts in a mask, so `pred` -- f64 arithmetic in the
+            // second round -- runs once per slot)
+            const bool cached = n <= 4096u;
+            unsigned long long mine = 0ull;
+            uint32_t total = 0;
+            for (uint32_t c = 0, e0 = 0; e0 < n; e0 += 64, ++c) {
+                const bool go = pred(e0 + (uint32_t)lane);
+                if (cached && go) mine |= 1ull << c;
+                total += (uint32_t)__popcll(__ballot(go));
             }
-            evaluated += (uint32_t)__popcll(__ballot(go));
-        }
-        __syncthreads();
+            for (uint32_t b0 = 0; b0 < total; b0 += 64) {
+                uint32_t w = 0;
+                for (uint32_t c = 0, e0 = 0; e0 < n && w < b0 + 64u; e0 += 64, ++c) {
+                    const uint32_t e = e0 + (uint32_t)lane;
+                    const bool go = cached ? ((mine >> c) & 1ull) != 0ull : pred(e);
+                    const unsigned long long m = __ballot(go);
+                    const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (go && pos >= b0 && pos < b0 + 64u) elist[pos - b0] = e;
+                    w += (uint32_t)__popcll(m);
+                }
+                __syncthreads();
+                if (b0 + (uint32_t)lane < total) {
+                    const uint32_t e = elist[lane];
+                    const uint32_t ix = sidx[e];
+                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
+                }
+                __syncthreads();
+            }
+            evaluated += total;
+        };
+        eval_packed([&](uint32_t e) { return e < n && (all || sfk[e] <= K1); });
         RR_STAMP(3);  // first evaluation round
         if (!all) {
             const KeyT dk1 = kth_smallest_keys<KeyT>(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
@@ -574,21 +610,15 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
             double rhs = 0.0;
             if (prune) rhs = proof_rhs<T>(dk1);
             const double qadd = qn ? qn[q] : 0.0;
-            for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                bool go = e < n && skey[e] == KMAX && sfk[e] > K1;
-                if (go && prune) {
-                    const uint32_t fk = sfk[e];
-                    const double L = (double)__uint_as_float((fk & 0x80000000u) ? (fk & 0x7FFFFFFFu) : ~fk);
-                    const double lb = proof_lb<T>(L, qadd, dim);
-                    go = !(lb > rhs);  // not provably farther than the kout-th exact distance found so far
-                }
-                if (go) {
-                    const uint32_t ix = sidx[e];
-                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
-                }
-                evaluated += (uint32_t)__popcll(__ballot(go));
-            }
+            // (the first round evaluated exactly the entries with a bound <= K1: the rest are the unevaluated ones)
+            eval_packed([&](uint32_t e) {
+                if (e >= n) return false;
+                const uint32_t fk = sfk[e];
+                if (fk <= K1) return false;
+                if (!prune) return true;
+                const double L = (double)__uint_as_float((fk & 0x80000000u) ? (fk & 0x7FFFFFFFu) : ~fk);
+                return !(proof_lb<T>(L, qadd, dim) > rhs);  // not provably farther than the kout-th exact distance so far
+            });
         }
     }
     __syncthreads();

@@ -7,7 +7,7 @@ from petal_neighbors_amd import _lib
 L = _lib.lib()
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-n, dim, nq = 1_000_000, 128, 10_000
+n, dim, nq = int(os.environ.get('PN_N', 1_000_000)), 128, 10_000
 pts = torch.empty((n, dim), dtype=torch.float32, device='cuda:0'); qs = torch.empty((nq, dim), dtype=torch.float32, device='cuda:0')
 L.pn_fill_uniform_device_f32(pts.data_ptr(), n * dim, 0x5EED0001, 0, 0, None); L.pn_fill_uniform_device_f32(qs.data_ptr(), nq * dim, 0x5EED0002, 0, 0, None)
 torch.cuda.synchronize()
@@ -31,8 +31,8 @@ print("  ... of which mid-run compactions %10.0f cycles in %.1f compactions (%.0
 print("  end of run (final compactions + publish) %10.0f cycles" % (cyc(5) / waves))
 print("  tile barrier incl. DMA wait %10.0f cycles = %4.1f %% of the run" % (cyc(6) / waves, 100.0 * cyc(6) / waves / run))
 print("  tile top to chain 1 (fragment + norm reads issued, LDS-DMA issue, check, rare path) %10.0f cycles = %4.1f %% of the run" % (cyc(8) / waves, 100.0 * cyc(8) / waves / run))
-print("  chain 1 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(9) / waves, 100.0 * cyc(9) / waves / run, cyc(9) / waves / 1302))
-print("  chain 2 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(10) / waves, 100.0 * cyc(10) / waves / run, cyc(10) / waves / 1302))
+print("  chain 1 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(9) / waves, 100.0 * cyc(9) / waves / run, cyc(9) / waves / max(n / 128 / 12 * 2, 1)))
+print("  chain 2 (16 MFMAs)  %10.0f cycles = %4.1f %% of the run (%.0f cycles per chain)" % (cyc(10) / waves, 100.0 * cyc(10) / waves / run, cyc(10) / waves / max(n / 128 / 12 * 2, 1)))
 print("  in-kernel clock (s_memtime / s_memrealtime x 100 MHz) %.3f GHz; run = %.3f ms" % (cyc(7) / max(cyc(11), 1) * 0.1, cyc(11) / waves * 1e-5))
 
 if out[12]:

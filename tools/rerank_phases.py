@@ -5,7 +5,7 @@ import petal_neighbors_amd as pn
 from petal_neighbors_amd import _lib
 L = _lib.lib()
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-n, dim, nq = 1_000_000, 128, 10_000
+n, dim, nq = int(os.environ.get("PN_N", 1_000_000)), 128, 10_000
 pts = torch.empty((n, dim), dtype=torch.float32, device='cuda:0'); qs = torch.empty((nq, dim), dtype=torch.float32, device='cuda:0')
 L.pn_fill_uniform_device_f32(pts.data_ptr(), n * dim, 0x5EED0001, 0, 0, None); L.pn_fill_uniform_device_f32(qs.data_ptr(), nq * dim, 0x5EED0002, 0, 0, None)
 torch.cuda.synchronize()
