@@ -303,7 +303,10 @@ __device__ __forceinline__ KeyT kth_smallest_regs(const KeyT *a, uint32_t n, uin
 __device__ __forceinline__ uint32_t kth_smallest_lds(const uint32_t *a, uint32_t n, uint32_t k, int lane) {
     uint32_t T = 0;
 #ifndef PN_DIAG_SELECT_LDS
+    if (n <= 128u) return kth_smallest_regs<uint32_t, 2>(a, n, k, lane);
+    if (n <= 192u) return kth_smallest_regs<uint32_t, 3>(a, n, k, lane);
     if (n <= 256u) return kth_smallest_regs<uint32_t, 4>(a, n, k, lane);
+    if (n <= 384u) return kth_smallest_regs<uint32_t, 6>(a, n, k, lane);
     if (n <= 512u) return kth_smallest_regs<uint32_t, 8>(a, n, k, lane);
 #endif
     for (int b = 31; b >= 0; --b) {
@@ -516,8 +519,14 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
                             if (seg_off[mid] <= e) lo = mid; else hi = mid - 1;
                         }
                         const size_t src = (((size_t)(s0 + lo) * nq_pad + q) * (size_t)cap + (e - seg_off[lo])) * (size_t)idx_stride;
-                        ixr[r] = cidx[src];
-                        fkr[r] = ckey[src];
+                        if (idx_stride == 2) {  // (key, row) pairs of the bf16 filter: one 8-byte load
+                            const uint2 pr = *reinterpret_cast<const uint2 *>(ckey + src);
+                            fkr[r] = pr.x;
+                            ixr[r] = pr.y;
+                        } else {
+                            ixr[r] = cidx[src];
+                            fkr[r] = ckey[src];
+                        }
                     }
                 }
 #pragma unroll
@@ -570,6 +579,8 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
         // chain -- for a handful of busy lanes.  So their positions are first packed into lists of 64 (ballot + prefix
         // count per chunk, no memory traffic), and a list is evaluated with one candidate per lane: one round for the
         // headline batch's first evaluation instead of three.  `pred` must not depend on what the evaluation writes.
+        KeyT lane_key = KMAX;      // the key this lane evaluated in the latest list
+        uint32_t list_total = 0;   // entries the latest call evaluated
         auto eval_packed = [&](auto pred) {
             // (up to 64 chunks: a lane remembers its slots' verdicts in a mask, so `pred` -- f64 arithmetic in the
             // second round -- runs once per slot)
@@ -592,19 +603,34 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(
                     w += (uint32_t)__popcll(m);
                 }
                 __syncthreads();
+                lane_key = KMAX;
                 if (b0 + (uint32_t)lane < total) {
                     const uint32_t e = elist[lane];
                     const uint32_t ix = sidx[e];
-                    if (ix < n_rows) skey[e] = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
+                    if (ix < n_rows) {
+                        lane_key = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
+                        skey[e] = lane_key;
+                    }
                 }
                 __syncthreads();
             }
             evaluated += total;
+            list_total = total;
         };
         eval_packed([&](uint32_t e) { return e < n && (all || sfk[e] <= K1); });
         RR_STAMP(3);  // first evaluation round
         if (!all) {
-            const KeyT dk1 = kth_smallest_keys<KeyT>(skey, n, (uint32_t)kout, lane);  // among the evaluated ones
+            // the kout-th smallest exact distance so far: a single list's keys are still in the lanes' registers
+            KeyT dk1;
+            if (list_total <= 64u) {
+                dk1 = 0;
+                for (int b = (int)sizeof(KeyT) * 8 - 1; b >= 0; --b) {
+                    const KeyT cand = dk1 | ((KeyT)1 << b);
+                    if ((uint32_t)__popcll(__ballot(lane_key < cand)) < (uint32_t)kout) dk1 = cand;
+                }
+            } else {
+                dk1 = kth_smallest_keys<KeyT>(skey, n, (uint32_t)kout, lane);
+            }
             RR_STAMP(4);  // k-th smallest exact distance so far
             const bool prune = dk1 < KINF;  // finite: else every candidate is evaluated
             double rhs = 0.0;
