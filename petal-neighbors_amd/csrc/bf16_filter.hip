@@ -1215,7 +1215,51 @@ struct BfShared {
     uint32_t epoch;   // 1 .. 4095, different from the previous launch on these buffers
     uint32_t rank;    // r: the shared threshold is the r-th smallest bound of the union
     uint32_t nseg;    // segments per query
+    // seed in the kernel (Bf16Shared in pn_internal.h): lists of the scout launch -> starting thresholds (main launch);
+    // words the scout launch sets to +inf
+    const float *seed_lists;
+    uint32_t seed_rank, seed_nq;
+    uint32_t *seed_words;
 };
+
+// Starting threshold of query q from the scout launch's lists (what bf16_seed_kernel computes, in the main launch's
+// prologue: a lane per query).  Every (segment, lane half) list is sorted ascending; the rank-th smallest of the union
+// of their first kSeedTake entries is the rank-th smallest of the whole union unless one list holds more than
+// kSeedTake of the rank smallest, and then it is larger -- a looser start, never an invalid one (ANY start is valid).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kSeedTake = 3;
+__device__ __forceinline__ float bf_seed_lane(const float *__restrict__ lists, size_t nq_pad, uint32_t nseg, uint32_t rank,
+                                              size_t q) {
+    const float inf = __uint_as_float(0x7F800000u);
+    float l[kScoutList];
+#pragma unroll
+    for (int i = 0; i < kScoutList; ++i) l[i] = inf;
+    auto insert = [&](float x) {  // keep the kScoutList smallest, ascending
+        float c = x;
+#pragma unroll
+        for (int i = 0; i < kScoutList; ++i) {
+            const float lo = fminf(l[i], c);
+            c = fmaxf(l[i], c);
+            l[i] = lo;
+        }
+    };
+    static_assert(kScoutList % 4 == 0 && kSeedTake <= 4, "list heads are read as one 16-byte load");
+    const f32x4_t *p = reinterpret_cast<const f32x4_t *>(lists + q * (size_t)(2 * kScoutList));
+    const size_t seg_stride = nq_pad * (size_t)(2 * kScoutList) / 4;  // in 16-byte words
+#pragma unroll 4
+    for (uint32_t sg = 0; sg < nseg; ++sg) {
+        const f32x4_t a = p[(size_t)sg * seg_stride], b = p[(size_t)sg * seg_stride + kScoutList / 4];
+#pragma unroll
+        for (int i = 0; i < kSeedTake; ++i) {
+            insert(a[i]);
+            insert(b[i]);
+        }
+    }
+    float r = l[0];
+#pragma unroll
+    for (int i = 1; i < kScoutList; ++i) r = (uint32_t)i + 1u == rank ? l[i] : r;
+    return r;
+}
 template <int KS, int M, bool RAD, bool CI, int MODE, bool CAPT, bool SH = false>
 __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restrict__ img, uint32_t n_tiles,
                                                              const u32x4 *__restrict__ Bq, uint32_t q_tiles,
@@ -1371,8 +1415,21 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
         if (t_scout < 4u) t_scout = 0;
         if (MODE == 2 || tau_init) {  // thresholds given by the caller (radius queries, shared seed): no scouting
             t_scout = 0;
-            tau0 = s2f(SH ? sh_load(tau_init + q0 + jq) : tau_init[q0 + jq]);
-            tau1 = s2f(SH ? sh_load(tau_init + q0 + 32 + jq) : tau_init[q0 + 32 + jq]);
+            if (MODE == 2 && !RAD && sh.seed_lists) {
+                // lane L derives query q0 + L's threshold (bf_seed_lane); the lanes (jq, h) then pick up their two.
+                // A padding query of the last tile gets -inf: nothing passes, it costs no appends.
+                const size_t ql = q0 + (size_t)lane;
+                float sd = __uint_as_float(0xFF800000u);
+                if (ql < (size_t)sh.seed_nq) {
+                    const uint32_t key = f2s(bf_seed_lane(sh.seed_lists, nq_pad, sh.nseg, sh.seed_rank, ql));
+                    sd = s2f(key == 0xFFFFFFFFu ? key : key + 1u);  // rows with a bound EQUAL to it still pass the strict '<'
+                }
+                tau0 = __shfl(sd, jq);
+                tau1 = __shfl(sd, 32 + jq);
+            } else {
+                tau0 = s2f(SH ? sh_load(tau_init + q0 + jq) : tau_init[q0 + jq]);
+                tau1 = s2f(SH ? sh_load(tau_init + q0 + 32 + jq) : tau_init[q0 + 32 + jq]);
+            }
         }
 #endif
         if (MODE == 1 || (MODE == 0 && scout_out)) {  // scout-only launch: every run contributes its lists
@@ -1446,6 +1503,9 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                     o0[i] = s0[i];
                     o1[i] = s1[i];
                 }
+                // seed in the kernel: the words the main launch's refreshers lower start at +inf (the main waves
+                // derive their own starting thresholds from the lists)
+                if (sh.seed_words && seg == 0u) sh_store(sh.seed_words + q0 + (size_t)lane, 0xFF800000u);
                 u0 = run_end;
                 continue;
             }
@@ -2365,6 +2425,17 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
                                 const uint32_t *tau_init, float *scout_out, const Bf16Shared *shp, hipStream_t s) {
     const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16 + 16;  // three tile buffers (software-pipelined main loop) + the arrival counter
     const uint32_t kp_keep = kp | ((uint32_t)(M == 1 && !RAD && cb.final_keep > (int)kp ? cb.final_keep : 0) << 16);
+    const bool use_sh = shp && shp->n_refresh > 0;
+    BfShared bsh{};
+    bsh.nseg = (uint32_t)cb.nseg;
+    if (shp) {
+        bsh.seed_lists = shp->seed_lists;
+        bsh.seed_rank = shp->seed_rank;
+        bsh.seed_nq = shp->seed_nq;
+        bsh.seed_words = shp->seed_words;
+        if (bsh.seed_lists && (bsh.seed_rank < 1 || bsh.seed_rank > (uint32_t)kScoutList || !bf16_seed_in_kernel(cb.nseg)))
+            return hipErrorInvalidValue;
+    }
 #define PN_BF_LAUNCH_MODE(MD)                                                                                          \
     {                                                                                                                   \
         auto kern = bf16_filter_kernel<KS, M, RAD, CI, MD, kBfCapture && (M > 1) && !RAD>;                                                             \
@@ -2374,16 +2445,21 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), sh, s, static_cast<const char *>(img), n_tiles,       \
                            static_cast<const u32x4 *>(B), q_tiles, kp_keep, static_cast<uint2 *>(cb.keys), cb.cnt,      \
                            static_cast<uint32_t *>(cb.tau), cb.nq_pad, split, spp, scout_max, tau_init, scout_out,      \
-                           BfShared{});                                                                                 \
+                           bsh);                                                                                        \
     }
-    if (shp) {  // shared thresholds: main pass with refresher workgroups behind the n_wg main ones
+    if (use_sh) {  // shared thresholds: main pass with refresher workgroups behind the n_wg main ones
         if constexpr (!RAD && M <= 2 && !kBfCapture) {
             if (!tau_init || scout_out || split != 1 || shp->n_refresh < 1) return hipErrorInvalidValue;
             auto kern = bf16_filter_kernel<KS, M, false, CI, 2, false, true>;
             static LdsAttrOnce lds_attr;
             const hipError_t e = lds_attr.ensure(reinterpret_cast<const void *>(kern), sh);
             if (e != hipSuccess) return e;
-            const BfShared a{shp->pcnt, shp->done, (uint32_t)n_wg, shp->epoch, shp->rank, (uint32_t)cb.nseg};
+            BfShared a = bsh;
+            a.pcnt = shp->pcnt;
+            a.done = shp->done;
+            a.n_main = (uint32_t)n_wg;
+            a.epoch = shp->epoch;
+            a.rank = shp->rank;
             hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg + shp->n_refresh)), dim3(256), sh, s,
                                static_cast<const char *>(img), n_tiles, static_cast<const u32x4 *>(B), q_tiles, kp_keep,
                                static_cast<uint2 *>(cb.keys), cb.cnt, static_cast<uint32_t *>(cb.tau), cb.nq_pad, split,
@@ -2412,7 +2488,7 @@ static hipError_t launch_bf16_m(const void *img, uint32_t n_tiles, const void *B
                                 const uint32_t *tau_init, bool radius, float *scout_out, const Bf16Shared *shp,
                                 hipStream_t s) {
     if (radius)
-        return cb.cap == 256 && tau_init && !shp ? launch_bf16_t<KS, 4, true, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg,
+        return cb.cap == 256 && tau_init && !(shp && shp->n_refresh > 0) ? launch_bf16_t<KS, 4, true, CI>(img, n_tiles, B, q_tiles, kp, cb, n_wg,
                                                                                   split, spp, scout_max, tau_init,
                                                                                   nullptr, nullptr, s)
                                                  : hipErrorInvalidValue;
@@ -2453,7 +2529,8 @@ hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B,
     const uint32_t n_tiles = (uint32_t)((n + kBP - 1) / kBP);
     const uint32_t q_tiles = (uint32_t)(cb.nq_pad / kBQ);
     if ((uint32_t)split > n_tiles) return hipErrorInvalidValue;
-    if (shp && (!(split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0) || !bf16_shared_supported(cb.cap) ||
+    if (shp && shp->n_refresh > 0 &&
+        (!(split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0) || !bf16_shared_supported(cb.cap) ||
                 shp->epoch < 1 || shp->epoch > 4095 || shp->rank < 1 || !shp->pcnt || !shp->done))
         return hipErrorInvalidValue;  // shared thresholds need the aligned partition (exactly nseg cells per query)
     const uint32_t spp = (uint32_t)mfma_v2_max_segments((size_t)q_tiles * split, n_wg);
@@ -2578,6 +2655,8 @@ hipError_t launch_bf16_seed(const float *lists, size_t nq_pad, int nseg, int ran
     return hipGetLastError();
 }
 int bf16_scout_list() { return kScoutList; }
+// the main launch derives its starting thresholds from the scout launch's lists itself when a lane can walk them all
+bool bf16_seed_in_kernel(int nseg) { return nseg >= 1 && nseg <= 32; }
 
 // radius queries: per-query threshold of the filter.  A row can only be within the radius when its exact squared
 // distance is below tau_r (computed by the host with the rounding allowances of select.hip's proof), hence when

@@ -261,8 +261,15 @@ int bf16_segments(size_t q_tiles, int n_wg, int split);
 struct Bf16Shared {
     uint32_t *pcnt, *done;
     uint32_t epoch, rank;
-    int n_refresh;
+    int n_refresh;  // 0: no shared thresholds (the seed fields below may still be set)
+    // Seed in the kernel (narrow rows, <= 32 segments): the scout-only launch is given `seed_words` ([nq_pad], set to
+    // +inf there: the words the refreshers lower), the main launch `seed_lists` (the scout launch's lists) + the rank
+    // and the number of real queries, and derives its starting thresholds itself -- no bf16_seed_kernel launch between
+    const float *seed_lists = nullptr;
+    uint32_t seed_rank = 0, seed_nq = 0;
+    uint32_t *seed_words = nullptr;
 };
+bool bf16_seed_in_kernel(int nseg);
 bool bf16_shared_supported(int cap);
 hipError_t launch_bf16_filter(const void *img, size_t n, int dim, const void *B, int kp, const CandBuf &cb, int n_wg,
                               int split, int scout_max, const uint32_t *tau_init, bool radius, float *scout_out,
