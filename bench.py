@@ -225,6 +225,21 @@ def verify_radius(out, q_host, n, dim, nq, radius, tree):
     return res
 
 
+def committed_traffic(kernel_name, config_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same command
+    (profiles/*pmc*.json: counters cannot be read in-process), or (None, None)."""
+    traffic, src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+            pmc = json.load(open(f))
+            if pmc.get("kernel") == kernel_name and pmc.get("config") == config_key:
+                traffic, src = pmc["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    return traffic, src
+
+
 def bench_f64(args):
     """--dtype f64: the same k-NN step on an f64 index (the reference is generic over A and its own harness is f64,
     benches/ball_tree.rs:9-13): the bf16 MFMA filter over the f64 corpus' tile images, then the f64 re-rank, proof and
@@ -283,6 +298,8 @@ def bench_f64(args):
     bf = args.engine in ("auto", "bf16") and tree.bf16_eligible
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     ms_per_step = elapsed / args.steps * 1e3
+    kernel_name = ("bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel") if bf else "exact_knn_kernel"
+    traffic, traffic_src = committed_traffic(kernel_name, args.config + "_f64")
     line = {
         "metric": f"exact k-NN queries/sec ({n} x {dim} fp64, k={k})", "value": round(nq * args.steps / elapsed, 1),
         "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -291,8 +308,10 @@ def bench_f64(args):
                                f"random bits", "n_points": n, "dim": dim, "n_queries": nq, "k": k,
                    "engine": "bf16 filter + f64 re-rank" if bf else "exact f64 scan"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
-                     "kernel": ("bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel") if bf else "exact_knn_kernel",
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     **({"traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})"}
+                        if traffic_src else {}),
+                     "kernel": kernel_name,
                      "mfma_dtype": "bf16" if bf else "none (f64 vector unit)", "kernel_ms": round(hot_ms, 4),
                      "flops_per_launch": flops_per_launch, "launches_per_step": round(launches / max(args.steps, 1), 2),
                      "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4)},
@@ -565,16 +584,8 @@ def main():
         # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same
         # command (counters cannot be read in-process); a committed summary is used when it describes
         # this kernel and config on one GPU, else null.
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
-                pmc = json.load(open(f))
-                if pmc.get("kernel") == kernel_name and world == 1 and \
-                        pmc.get("config") == args.config + ("_radius" if args.mode == "radius" else ""):
-                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-        except Exception:
-            pass
+        traffic, traffic_src = (None, None) if world != 1 else \
+            committed_traffic(kernel_name, args.config + ("_radius" if args.mode == "radius" else ""))
         if args.mode == "radius":
             kernel_name = "bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel"
         line = {
