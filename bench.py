@@ -61,6 +61,7 @@ CONFIGS = {
     "c2s8": (125_000, 128, 10_000, 10),
     "c5m": (1_000_000, 96, 200_000, 10),         # many queries: one workgroup per query tile
     "c3m": (1_000_000, 128, 200_000, 100),
+    "c3k10": (10_000_000, 128, 100_000, 10),     # configs[2]'s corpus and batch at k = 10 (grid in rounds, short buffers)
     "d64": (1_000_000, 64, 10_000, 10),          # narrower rows (kernel experiments)
     "d64k100": (1_000_000, 64, 10_000, 100),
 }

@@ -1231,7 +1231,17 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     p.split = 1;
     if (level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0)
         while (p.split < 8 && kp_for(p.split) > 96.0 && r_tiles / (size_t)(2 * p.split) >= 256) p.split *= 2;
-    const double kp = kp_for(p.split);
+    double kp = kp_for(p.split);
+    // A k' between 17 and 31 lives in 128-slot buffers anyway, so the tail it is planned against costs nothing but
+    // candidates there: the count of relevant rows varies from query to query (22 +- 5.3, up to 44 of 256 queries for
+    // k = 10: heavier than Poisson), and the queries at the upper end are the ones that overflow a segment.  Measured,
+    // 10M x 128, 10^5 queries, k = 10, 5 segments: k' = 20 left 15 queries per batch to the second tier -- 15 exact
+    // scans of 10^7 rows, 22 of the step's 215 ms; planned for twice the mean (k' = 30): see DESIGN.md 4.0.
+    if (level == 0 && ix->filter_slots == 0 && kp > 16.0 && kp < 32.0) {
+        const double per2 = 2.0 * R / (double)(per_tile * (size_t)p.split);
+        const double v = per2 + n_sigma * std::sqrt(per2) + 3.0;
+        kp = v < 32.0 ? (v > kp ? v : kp) : 32.0;
+    }
     p.kp = (int)std::ceil(kp);
     p.ok = level < 2 && p.kp + 32 <= 256;
     p.cap = p.ok ? bf16_cap_for(p.kp) : 0;
@@ -1252,24 +1262,36 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     if (p.ok && level == 0 && ix->filter_slots == 0 && p.split == 1 && per_tile >= 2 &&
         p.n_wg % (int)q_tiles == 0) {
         const size_t run_len = r_tiles / per_tile;
-        double lam_target = 1.2;
+        // How large a sample: its share of the corpus is lambda / R, and the seed lands at the corpus' rank
+        // seed_rank(lambda) R / lambda -- ~7.5 R at lambda = 1.2, ~3 R at 9.  For k = 10 (R = 24) lambda = 1.2 is a
+        // twentieth of the corpus and the best of 0.3 ... 2.4 (C2: 2.39 / 2.43 / 2.49 ms at 1.2 / 1.8 / 2.4); for k = 100
+        // (R = 244) it was 0.5 % of the corpus, every buffer took 135 appends for 42 kept, and larger samples pay:
+        // 1M x 128, k = 100: 3.89 / 3.73 / 3.64 / 3.44 / 3.36 / 3.43 ms per step at lambda = 1.2 / 2.4 / 4 / 6 / 9 / 12;
+        // 10M x 128, 10^5 queries, k = 100 (same device): 223 (64-tile cap) / 218 / 213 / 209 ms at 1.2 / 1.2 / 4 / 9.
+        // The cap of 64 tiles per workgroup (from the in-run scout of round 1) is gone: an eighth of the run bounds it.
+        double lam_target = R / 27.0 > 1.2 ? R / 27.0 : 1.2;
         if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_target = atof(e);  // experiments only
-        double t = lam_target * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup for lambda = 1.2
-        if (t > 64.0) t = 64.0;
+        double t = lam_target * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
         p.scout_tiles = (int)t;
         if (p.scout_tiles < 1 && run_len >= 8) p.scout_tiles = 1;  // short runs of many segments: one tile each is a large sample
-        if (p.scout_tiles >= 4 || (p.scout_tiles >= 1 && run_len < 64)) {
+        // (every (segment, lane half) list keeps its kScoutList smallest: the union's seed_rank-th smallest is exact
+        // unless ONE of the 2 nseg lists holds more than kScoutList of them, and then it comes out larger -- a looser
+        // seed, never an invalid one.  With rank / (2 nseg) <= 3 expected per list that does not happen; a sample whose
+        // rank would exceed that is shrunk until it fits.)
+        while (p.scout_tiles >= 4 || (p.scout_tiles >= 1 && run_len < 64)) {
             const double lam = R * (double)p.scout_tiles * (double)per_tile / (double)r_tiles;
             double term = std::exp(-lam), cdf = term;  // P(X <= 0)
             int rank = 1;
-            while (1.0 - cdf > 1e-7 && rank < 2 * bf16_scout_list()) {  // 1 - cdf = P(X >= rank)
+            while (1.0 - cdf > 1e-7 && rank < 96) {  // 1 - cdf = P(X >= rank)
                 term *= lam / (double)rank;
                 cdf += term;
                 ++rank;
             }
             p.seed_rank = rank < 5 ? 5 : rank;
-            p.shared_scout = p.seed_rank <= bf16_scout_list();
+            p.shared_scout = p.seed_rank < 96 && p.seed_rank <= 6 * p.nseg;
+            if (p.shared_scout || p.scout_tiles < 8) break;
+            p.scout_tiles = p.scout_tiles * 3 / 4;
         }
     }
 #endif
@@ -1294,6 +1316,11 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
             p.sh_rank = rank;
         }
     }
+    if (getenv("PN_DEBUG_PLAN"))  // development aid: what a call was planned as
+        fprintf(stderr, "bf16_plan: n %zu q_tiles %zu k %zu R %.0f: n_wg %d per_tile %zu split %d nseg %d kp %d cap %d aligned %d "
+                        "shared_scout %d scout_tiles %d seed_rank %d scout_max %d n_refresh %d sh_rank %d\n",
+                ix->n, q_tiles, kout, R, p.n_wg, per_tile, p.split, p.nseg, p.kp, p.cap, (int)p.aligned, (int)p.shared_scout,
+                p.scout_tiles, p.seed_rank, p.scout_max, p.n_refresh, p.sh_rank);
     return p;
 }
 // f32 MFMA filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for flagged queries
