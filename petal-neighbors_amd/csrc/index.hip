@@ -1132,8 +1132,11 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
 #ifndef PN_DIAG_NO_SHARED_SCOUT
     if (p.ok && level == 0 && ix->filter_slots == 0 && segs >= 4.0) {
         const size_t run_len = q_tiles * r_tiles / (size_t)p.n_wg;
-        double t = 1.2 * (double)ix->n / (R * segs * 128.0);  // tiles per run for lambda = 1.2
-        if (t > 16.0) t = 16.0;
+        double lam_w = 1.2, t_cap_w = 16.0;
+        if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_w = atof(e);  // experiments only
+        if (const char *e = getenv("PN_EXP_SCOUT_CAP")) t_cap_w = atof(e);   // experiments only
+        double t = lam_w * (double)ix->n / (R * segs * 128.0);  // tiles per run for lambda = 1.2
+        if (t > t_cap_w) t = t_cap_w;
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
         p.scout_tiles = (int)t;
         if (p.scout_tiles >= 1) {
