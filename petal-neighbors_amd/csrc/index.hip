@@ -1271,11 +1271,12 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         // (R = 244) it was 0.5 % of the corpus, every buffer took 135 appends for 42 kept, and larger samples pay:
         // 1M x 128, k = 100: 3.89 / 3.73 / 3.64 / 3.44 / 3.36 / 3.43 ms per step at lambda = 1.2 / 2.4 / 4 / 6 / 9 / 12;
         // 10M x 128, 10^5 queries, k = 100 (same device): 223 (64-tile cap) / 218 / 213 / 209 ms at 1.2 / 1.2 / 4 / 9.
-        // The cap of 64 tiles per workgroup (from the in-run scout of round 1) is gone: an eighth of the run bounds it.
+        // The cap of 64 tiles per workgroup (from the in-run scout of round 1) is gone: a nineteenth of the run bounds it.
         double lam_target = R / 27.0 > 1.2 ? R / 27.0 : 1.2;
         if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_target = atof(e);  // experiments only
         double t = lam_target * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup
-        if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
+        // (never more than a nineteenth of the run -- what lambda = 1.2 asks for at k = 10; k = 1 would ask for a fifth)
+        if (t > (double)run_len / 19.0) t = (double)run_len / 19.0;
         p.scout_tiles = (int)t;
         if (p.scout_tiles < 1 && run_len >= 8) p.scout_tiles = 1;  // short runs of many segments: one tile each is a large sample
         // (every (segment, lane half) list keeps its kScoutList smallest: the union's seed_rank-th smallest is exact
