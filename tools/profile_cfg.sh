@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/profile_cfg.sh <config> <tag>  -- rocprofv3 kernel-trace stats of one bench configuration
+# usage (GPU box): tools/profile_cfg.sh <config> <tag> ["<more bench args>"] [steps]  -- rocprofv3 kernel-trace stats of one bench configuration
 cd /tmp && export TMPDIR=/tmp
-C=${1:-c2}; T=${2:-rXX}
+C=${1:-c2}; T=${2:-rXX}; X=${3:-}; K=${4:-20}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_${T}_$C
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $C --steps 20 --warmup 3 --no-cpu-baseline --no-verify > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $C --steps $K --warmup 3 --no-cpu-baseline --no-verify $X > $O/bench.json 2> $O/bench.err
 rm -f $O/*kernel_trace.csv
 python3 - <<PY
 import csv
