@@ -353,3 +353,33 @@ def test_shared_thresholds_only_change_the_candidate_count(pn, oracle_mod):
     assert got[0][3] <= 3 and got[1][3] <= 3          # benign data: (nearly) everything proven, with or without
     assert got[1][2] < got[0][2]                      # the default rank keeps fewer candidates than no sharing
     assert got[2][3] > nq // 2                        # r = 2: most queries of its first call went to the next tier
+
+
+def test_large_k_takes_a_sample_sized_by_its_relevant_rows(pn, oracle_mod):
+    """k = 100: the shared scout's sample holds ~9 of the ~244 relevant rows (lambda = R / 27), the seed is a rank beyond
+    the 12 a lane's list holds (merged by the seed kernel, not the main launch's prologue), and buffers of 128 slots
+    are planned for twice the mean count.  Whatever the seed, the answers are the oracle's."""
+    n, dim, nq, k = 200_000, 32, 600, 100
+    pts, qs = uniform((n, dim), 4101), uniform((nq, dim), 4102)
+    tree, st = _check(pn, oracle_mod, pts, qs, k)
+    assert st["fallback_queries"] <= nq // 50, st       # the tier served the batch
+    assert st["candidates"] / st["queries"] >= k, st
+
+
+def test_radius_reruns_of_a_few_dense_queries_on_a_larger_corpus(pn, oracle_mod):
+    """The handful of queries whose survivor lists overflow are re-run exactly over up to 1024 row segments (the
+    two-pass CSR scan with per-(query, segment) offsets): same lists as the oracle's, ascending."""
+    rng = np.random.default_rng(23)
+    base = uniform((600_000, 16), 4201)
+    clump = (base[777] + 0.002 * rng.standard_normal((4000, 16))).astype(np.float32)
+    pts = np.concatenate([base, clump]).astype(np.float32)
+    qs = np.concatenate([uniform((30, 16), 4202), clump[:2] + np.float32(0.0005)]).astype(np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    _, d = oracle_mod.brute_knn(pts, qs[:30], 3)
+    r = float(np.median(d[:, 2]))
+    off, idx = tree.query_radius_batch(qs, r)
+    for a in range(len(qs)):
+        want = oracle_mod.brute_radius(pts, qs[a], np.float32(r))
+        assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), a
+    st = tree.stats()
+    assert 1 <= st["fallback_queries"] <= 4, st
