@@ -2322,6 +2322,11 @@ int bf16_cell_max(int kp, int cap, int nseg, bool wide) {
     return cap;
 #else
     const int cut = kp < cap ? kp : cap;
+#ifdef PN_DIAG_BF_FINALKEEP128  // experiment: 128-slot buffers end their runs uncut up to this many entries.  Measured at
+    // 1M x 128, k = 100 (k' = 42, 65 entries per buffer at the end of a run, the cut 4.9 % of a wave's run): kernel 2.86
+    // -> 2.81 / 2.75 ms at 64 / 96 entries, step 3.29 -> 3.35 / 3.54 -- the re-rank's LDS and gather lose more: not used.
+    if (!wide && cap == 128 && nseg >= 1) return (PN_DIAG_BF_FINALKEEP128) > cut ? (PN_DIAG_BF_FINALKEEP128) : cut;
+#endif
     if (wide || cap != 64 || nseg < 1) return cut;
     // 64-slot buffers of the narrow kernel end a run uncut up to `keep` entries (CandBuf::final_keep; the kernel's end of
     // run has the measurements): as many as keep the re-rank's LDS -- 12 bytes per slot a query's cells can hold -- near
@@ -2424,7 +2429,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
                                 const uint32_t *tau_init, float *scout_out, const Bf16Shared *shp, hipStream_t s) {
     const size_t sh = (size_t)3 * kBP * (2 * KS + 1) * 16 + 16;  // three tile buffers (software-pipelined main loop) + the arrival counter
-    const uint32_t kp_keep = kp | ((uint32_t)(M == 1 && !RAD && cb.final_keep > (int)kp ? cb.final_keep : 0) << 16);
+    const uint32_t kp_keep = kp | ((uint32_t)(M <= 2 && !RAD && cb.final_keep > (int)kp ? cb.final_keep : 0) << 16);
     const bool use_sh = shp && shp->n_refresh > 0;
     BfShared bsh{};
     bsh.nseg = (uint32_t)cb.nseg;
