@@ -254,16 +254,20 @@ __device__ __forceinline__ float exact_distance_f32(const float *__restrict__ q,
 // whole cost of the re-rank kernel.  len must be a multiple of 4 (device rows are zero padded to a multiple of 8:
 // the padding adds (0-0)*(0-0) = +0, which leaves every partial sum unchanged).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef PN_DIAG_RR_PREFETCH
+#define PN_DIAG_RR_PREFETCH 16
+#endif
 __device__ __forceinline__ float exact_distance_prefetched_f32(const float *qs, const float *__restrict__ p, int len) {
 #pragma clang fp contract(off)
     float s = 0.0f;
-    for (int k0 = 0; k0 < len; k0 += 64) {
-        f32x4_t v[16];
+    constexpr int NV = PN_DIAG_RR_PREFETCH;  // 16-byte loads in flight per round
+    for (int k0 = 0; k0 < len; k0 += 4 * NV) {
+        f32x4_t v[NV];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < NV; ++i)
             if (k0 + 4 * i < len) v[i] = *reinterpret_cast<const f32x4_t *>(p + k0 + 4 * i);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             if (k0 + 4 * i < len) {
                 const f32x4_t a = *reinterpret_cast<const f32x4_t *>(qs + k0 + 4 * i);
                 float d;
@@ -430,8 +434,11 @@ extern "C" int pn_debug_read_rr(unsigned long long *out, int nq) {
 #else
 #define RR_STAMP(i) ((void)0)
 #endif
+#ifndef PN_DIAG_RR_WAVES
+#define PN_DIAG_RR_WAVES 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(64) void select_rerank_kernel(
+__global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const T *__restrict__ P, size_t ldp, const T *__restrict__ Q,
     size_t ldq, int dim, uint32_t n_rows, int kout, uint64_t index_base, uint64_t *__restrict__ idx_out,
