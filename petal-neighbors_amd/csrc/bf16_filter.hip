@@ -257,6 +257,188 @@ __global__ void bf16_pack_corpus_kernel(const T *__restrict__ P, const float *__
     at(E + 4) = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
 }
 
+// Eight lanes per row (narrow rows): lane `sub` of a row owns the CH = 2 KS columns [sub CH, sub CH + CH) -- 16-byte
+// loads from the padded rows, its part of the three f64 sums, an 8-lane butterfly for the row's totals (any summation
+// order is inside the 2^-40 the norms are widened by) -- what bf16_pack_queries8_kernel does for queries.  The
+// thread-per-row kernels below read their rows one 4-byte element at a time, 64 rows' lines per instruction, and wrote
+// the image in 2-byte stores twice (zero fill, then values): 1M x 128 took 3.46 ms to pack and 2.1 ms for the row
+// statistics -- 0.23 TB/s.  x[i] (centred coordinate, f64) and hb[i] (its bf16) of column c0 + i; columns at or beyond
+// dim are zero.  Returns false for a non-finite coordinate in the lane's part.
+template <typename T>
+__device__ __forceinline__ bool bf_row_part8(const T *__restrict__ src, const float *__restrict__ mu, int dim, size_t ld,
+                                             int c0, int CH, bool in_rows, uint16_t (&hb)[18], double &pn, double &en,
+                                             double &hn) {
+    T xf[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) xf[i] = (T)0;
+    constexpr int VE = 16 / (int)sizeof(T);  // elements per 16-byte access
+    const bool vec = (CH % 4) == 0 && c0 + CH <= (int)ld;  // (rows of the padded copy are 32-byte aligned, ld a multiple of 8)
+    if (in_rows) {
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < 18; i += VE)
+                if (i + VE <= CH) {
+                    typedef T tv_ __attribute__((ext_vector_type(VE)));
+                    const tv_ t4 = *reinterpret_cast<const tv_ *>(src + c0 + i);
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) xf[i + j] = t4[j];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i)
+                if (i < CH && c0 + i < dim) xf[i] = src[c0 + i];
+        }
+    }
+    bool finite = true;
+    pn = 0.0;
+    en = 0.0;
+    hn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        hb[i] = 0;
+        const int k = c0 + i;
+        if (i < CH && k < dim && in_rows) {
+            const double x = (double)xf[i];
+            finite = finite && (fabs(x) < 1.0e30);  // also false for NaN
+            const double c = x - (double)mu[k];  // centred coordinate (header: translation)
+            const float cf = (float)c;
+            hb[i] = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);  // 2^-60
+            const double xh = (double)bf_f(hb[i]);
+            pn += c * c;
+            en += (c - xh) * (c - xh);
+            hn += xh * xh;
+        }
+    }
+    uint32_t fin = finite ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        pn += __shfl_xor(pn, d);
+        en += __shfl_xor(en, d);
+        hn += __shfl_xor(hn, d);
+        fin &= (uint32_t)__shfl_xor((int)fin, d);
+    }
+    return fin != 0u;
+}
+
+// narrow rows: the image of row r is CP = 2 KS + 1 chunks of 8 bf16 -- 16 KS data columns, then the padding chunk (CI:
+// the f32 norms of the tile's rows 4 rr .. 4 rr + 3 in the padding chunk of its row rr < 16)
+template <typename T>
+__global__ void bf16_pack_corpus8_kernel(const T *__restrict__ P, const float *__restrict__ mu, size_t n, int dim,
+                                         size_t ld, int KS, uint16_t *__restrict__ img, size_t n_rows_img,
+                                         uint32_t *__restrict__ bad, int ci) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = t >> 3;
+    const int sub = (int)(t & 7);
+    if (r >= n_rows_img) return;  // (whole groups of eight leave together: n_rows_img * 8 is a multiple of the block size)
+    const int CP = 2 * KS + 1, CH = 2 * KS, E = bf16_extra_col(dim);
+    const int c0 = sub * CH;
+    uint16_t v[18];
+    double pn, en, hn;
+    const bool in_rows = r < n;
+    const bool finite = bf_row_part8<T>(P + r * ld, mu, dim, ld, c0, CH, in_rows, v, pn, en, hn);
+    const bool ok = in_rows && finite && (pn < 1.2676506002282294e30);  // 2^100
+    if (in_rows && !ok && sub == 0) atomicOr(bad, 1u);
+    uint16_t *row = img + r * (size_t)CP * 8;
+    if (!ci) {  // the five extra columns: |p|^2 (1 - g) rounded down in three truncated bf16 pieces, then the error terms
+        uint16_t x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;
+        if (!in_rows) {
+            x0 = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+        } else if (!ok) {
+            x0 = 0x7F80u;
+        } else {
+            double rem = pn * (1.0 - kG) / kUp;
+            x0 = bf_trunc(f_down(rem));
+            rem -= (double)bf_f(x0);
+            x1 = bf_trunc(f_down(rem));
+            rem -= (double)bf_f(x1);
+            x2 = bf_trunc(f_down(rem));
+            const double e_n = sqrt(en) * kUp, h_n = sqrt(hn) * kUp, p_n = sqrt(pn) * kUp;
+            x3 = bf_up(f_up((2.0 * e_n + 2.0 * kG * h_n) * (1.0 + 2.0 * kG)));
+            x4 = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int k = c0 + i;
+            if (i < CH) {
+                if (k == E + 0) v[i] = x0;
+                if (k == E + 1) v[i] = x1;
+                if (k == E + 2) v[i] = x2;
+                if (k == E + 3) v[i] = x3;
+                if (k == E + 4) v[i] = x4;
+            }
+        }
+    }
+    uint16_t *dst = row + c0;
+#pragma unroll
+    for (int i = 0; i < 18; i += 2)
+        if (i + 2 <= CH) *reinterpret_cast<uint32_t *>(dst + i) = (uint32_t)v[i] | ((uint32_t)v[i + 1] << 16);
+    // the padding chunk: zero, except that (CI) the tile's first 16 rows carry the 64 row norms, written by those rows
+    const size_t rr = r % kBP;
+    if (sub == 1 && !(ci && rr < 16)) {
+        typedef uint32_t u4_ __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u4_ *>(row + (size_t)(CP - 1) * 8) = u4_{0u, 0u, 0u, 0u};
+    }
+    if (ci && sub == 0) {  // |p|^2 (1 - g), rounded down to f32: the chain's initial accumulator value
+        const size_t tl = r / kBP;
+        float *norm_slot = reinterpret_cast<float *>(img + ((tl * kBP + rr / 4) * (size_t)CP + (size_t)(CP - 1)) * 8) + (rr % 4);
+        *norm_slot = ok ? f_down(pn * (1.0 - kG) / kUp) : 1.7e38f;
+    }
+}
+
+// the row statistics (below), eight lanes per row; a grid-stride loop and one set of atomics per WORKGROUP (a set per
+// wave -- 125 k waves on four addresses -- took 5.9 ms for 1M rows, more than the thread-per-row kernel it replaced)
+template <typename T>
+__global__ __launch_bounds__(256) void bf16_row_stats8_kernel(const T *__restrict__ P, const float *__restrict__ mu,
+                                                              size_t n, int dim, size_t ld, int KS, size_t rows,
+                                                              double *__restrict__ out) {
+    const int sub = (int)(threadIdx.x & 7);
+    const int CH = 2 * KS;
+    double bm = 0.0, dm = 0.0, bs = 0.0, ds = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;  // a multiple of 64: whole waves take every trip together
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 8; t += stride) {
+        const size_t r = t >> 3;
+        uint16_t v[18];
+        double pn, en, hn;
+        const bool in_rows = r < n;
+        const bool finite = bf_row_part8<T>(P + (in_rows ? r : 0) * ld, mu, dim, ld, sub * CH, CH, in_rows, v, pn, en, hn);
+        if (in_rows && sub == 0 && finite && pn < 1.2676506002282294e30) {
+            const double bp = (2.0 * sqrt(en) * kUp + 2.0 * kG * sqrt(hn) * kUp) * (1.0 + 2.0 * kG) * kUp;
+            const double dp = 2.0 * sqrt(pn) * kUp * (1.0 + 2.0 * kG) * kUp;
+            bm = fmax(bm, bp);
+            dm = fmax(dm, dp);
+            bs += bp;
+            ds += dp;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        bm = fmax(bm, __shfl_xor(bm, d));
+        dm = fmax(dm, __shfl_xor(dm, d));
+        bs += __shfl_xor(bs, d);
+        ds += __shfl_xor(ds, d);
+    }
+    __shared__ double red[4][4];
+    const int wave = (int)(threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) {
+        red[wave][0] = bm;
+        red[wave][1] = dm;
+        red[wave][2] = bs;
+        red[wave][3] = ds;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            bm = fmax(bm, red[w][0]);
+            dm = fmax(dm, red[w][1]);
+            bs += red[w][2];
+            ds += red[w][3];
+        }
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(bm));
+        atomicMax(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)__double_as_longlong(dm));
+        atomicAdd(out + 2, bs);
+        atomicAdd(out + 3, ds);
+    }
+}
+
 // The per-row constants Bp, Dp of the bound over the whole corpus (f64, before their bf16 rounding): out[0] = max Bp,
 // out[1] = max Dp (bit patterns of non-negative doubles order like integers), out[2] = sum Bp, out[3] = sum Dp.
 // Decides whether the CI layout serves this corpus and provides the maxima E(q) is built from.
@@ -2366,6 +2548,15 @@ template hipError_t launch_bf16_column_sums<double>(const double *, size_t, int,
 template <typename T>
 hipError_t launch_bf16_row_stats(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
                                  hipStream_t s) {
+#ifndef PN_DIAG_BF_PACK1
+    if (!bf16_is_wide(dim)) {  // (row statistics decide about the CI layout: its step count bounds the columns a lane owns)
+        const size_t rows = (n + 31) / 32 * 32;  // whole blocks of 256 threads = 32 rows
+        const size_t blocks = rows * 8 / 256;
+        hipLaunchKernelGGL(bf16_row_stats8_kernel<T>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, P, mu,
+                           n, dim, ld, bf16_ks_for(dim, false), rows, out4);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(bf16_row_stats_kernel<T>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld, out4);
     return hipGetLastError();
 }
@@ -2378,6 +2569,13 @@ hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int di
     const bool wide = bf16_is_wide(dim);
     if (wide && ci) return hipErrorInvalidValue;
     const size_t rows = wide ? (n + kWR - 1) / kWR * kWR : (n + kBP - 1) / kBP * kBP;
+#ifndef PN_DIAG_BF_PACK1
+    if (!wide) {  // rows is a multiple of 64: whole blocks of 256 threads = 32 rows
+        hipLaunchKernelGGL(bf16_pack_corpus8_kernel<T>, dim3((unsigned)(rows * 8 / 256)), dim3(256), 0, s, P, mu, n, dim, ld,
+                           bf16_ks_for(dim, ci), static_cast<uint16_t *>(img), rows, bad, ci ? 1 : 0);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(bf16_pack_corpus_kernel<T>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, P, mu, n, dim, ld,
                        bf16_ks_for(dim, ci), static_cast<uint16_t *>(img), rows, bad, wide ? 1 : 0, ci ? 1 : 0);
     return hipGetLastError();
