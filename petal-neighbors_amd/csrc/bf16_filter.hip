@@ -539,6 +539,130 @@ __global__ void bf16_pack_queries_kernel(const T *__restrict__ Q, const float *_
     qbad[q] = ok ? 0u : 1u;
 }
 
+// Wide rows (corpus and queries share the K-chunked layout), EIGHT lanes per row: lane `sub` packs the 16-byte slots
+// sub, sub + 8, ... (8 columns each: two 16-byte loads, one 16-byte store at the slot's swizzled place), the three f64
+// sums go through an 8-lane butterfly, and the slot(s) holding the five extra values are stored last, by their owners,
+// with the values in place.  The thread-per-row kernels (kept below for reference builds, -DPN_DIAG_BF_PACK1) wrote
+// every row twice in 2-byte stores: 1M x 768 took 21.4 ms to pack, 10^4 queries 0.28 ms of every step.
+template <typename T, bool QRY>
+__global__ void bf16_pack_wide8_kernel(const T *__restrict__ X, const float *__restrict__ mu, size_t n_valid,
+                                       size_t n_rows_img, int dim, size_t ld, uint16_t *__restrict__ img,
+                                       double *__restrict__ qn, uint32_t *__restrict__ qbad, uint32_t *__restrict__ bad) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = t >> 3;
+    const int sub = (int)(t & 7);
+    if (r >= n_rows_img) return;  // (whole groups of eight leave together)
+    const int n_slots = 8 * bf16_wide_nkc(dim) + (bf16_wide_has_x(dim) ? 2 : 0);
+    const int E = bf16_extra_col(dim);
+    const int gx0 = E >> 3, gx1 = (E + 4) >> 3;  // the slot(s) of the extra columns
+    const bool in_rows = r < n_valid;
+    const T *src = X + r * ld;
+    double s = 0.0, en = 0.0, hn = 0.0;
+    bool finite = true;
+    typedef uint32_t u4_ __attribute__((ext_vector_type(4)));
+    auto pack8 = [](const uint16_t (&v)[8]) {
+        return u4_{(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                   (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+    };
+    uint16_t vx[2][8];  // this lane's extras slot(s), stored after the totals are known
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vx[0][j] = 0; vx[1][j] = 0; }
+    for (int g = sub; g < n_slots; g += 8) {
+        const int k0 = 8 * g;
+        uint16_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0;
+        if (in_rows && k0 < dim) {
+            T xf[8];
+            constexpr int VE = 16 / (int)sizeof(T);
+            typedef T tv_ __attribute__((ext_vector_type(VE)));
+#pragma unroll
+            for (int i = 0; i < 8; i += VE) {  // (rows are zero padded to ld >= 64 nkc columns, 32-byte aligned)
+                const tv_ tt = *reinterpret_cast<const tv_ *>(src + k0 + i);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) xf[i + j] = tt[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k0 + j < dim) {
+                    const double x = (double)xf[j];
+                    finite = finite && (fabs(x) < 1.0e30);  // also false for NaN
+                    const double c = x - (double)mu[k0 + j];
+                    const float cf = (float)c;
+                    const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);  // 2^-60
+                    const float xh = bf_f(hb);
+                    v[j] = QRY ? bf_rne(-2.0f * xh) : hb;  // (queries: exact, a power-of-two multiple of a bf16 value)
+                    s += c * c;
+                    const double e = c - (double)xh;
+                    en += e * e;
+                    hn += (double)xh * (double)xh;
+                }
+            }
+        }
+        if (g == gx0 || g == gx1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vx[g == gx0 ? 0 : 1][j] = v[j];
+        } else {
+            *reinterpret_cast<u4_ *>(img + bf_wide_at(r, k0, dim)) = pack8(v);
+        }
+    }
+    uint32_t fin = finite ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        s += __shfl_xor(s, d);
+        en += __shfl_xor(en, d);
+        hn += __shfl_xor(hn, d);
+        fin &= (uint32_t)__shfl_xor((int)fin, d);
+    }
+    const bool ok = fin != 0u && (s < 1.2676506002282294e30);  // 2^100 (padding rows: sums of nothing)
+    uint16_t x[5] = {0, 0, 0, 0, 0};
+    if (QRY) {
+        x[0] = x[1] = x[2] = 0x3F80u;  // 1.0
+        if (ok) {
+            x[3] = (uint16_t)(bf_up(f_up(sqrt(hn) * kUp)) | 0x8000u);  // -Aq
+            x[4] = (uint16_t)(bf_up(f_up(sqrt(en) * kUp)) | 0x8000u);  // -Cq
+        }
+    } else if (!in_rows) {
+        x[0] = 0x7F00u;  // 1.7e38: never among the k' smallest of real rows (select.hip drops rows >= n anyway)
+    } else if (!ok) {
+        x[0] = 0x7F80u;
+    } else {  // |p|^2 (1 - g), rounded down, in three truncated bf16 pieces, then the two error terms
+        double rem = s * (1.0 - kG) / kUp;
+        x[0] = bf_trunc(f_down(rem));
+        rem -= (double)bf_f(x[0]);
+        x[1] = bf_trunc(f_down(rem));
+        rem -= (double)bf_f(x[1]);
+        x[2] = bf_trunc(f_down(rem));
+        const double e_n = sqrt(en) * kUp, h_n = sqrt(hn) * kUp, p_n = sqrt(s) * kUp;
+        x[3] = bf_up(f_up((2.0 * e_n + 2.0 * kG * h_n) * (1.0 + 2.0 * kG)));
+        x[4] = bf_up(f_up(2.0 * p_n * (1.0 + 2.0 * kG)));
+    }
+    const bool zero_data = QRY && !ok;  // keep the arithmetic finite; the query is re-run exactly
+    if (zero_data)
+        for (int g = sub; g < n_slots; g += 8)
+            if (g != gx0 && g != gx1) *reinterpret_cast<u4_ *>(img + bf_wide_at(r, 8 * g, dim)) = u4_{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int g = w == 0 ? gx0 : gx1;
+        if ((w == 1 && gx1 == gx0) || (g & 7) != sub || g >= n_slots) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            if (zero_data) vx[w][j] = 0;
+            if (k >= E && k < E + 5) vx[w][j] = x[k - E];
+        }
+        *reinterpret_cast<u4_ *>(img + bf_wide_at(r, 8 * g, dim)) = pack8(vx[w]);
+    }
+    if (sub == 0) {
+        if (QRY) {
+            qn[r] = ok ? s / kUp : 0.0;
+            qbad[r] = ok ? 0u : 1u;
+        } else if (in_rows && !ok) {
+            atomicOr(bad, 1u);
+        }
+    }
+}
+
 // The same for narrow rows with EIGHT lanes per query, each packing a contiguous eighth of the K columns (2 KS of
 // them): coalesced 16-byte loads and stores instead of one thread walking 128 coordinates and storing them two bytes at
 // a time (C2: 37 -> ~8 us per batch).  The three f64 sums are reduced over the eight lanes; their rounding differs
@@ -2570,6 +2694,11 @@ hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int di
     if (wide && ci) return hipErrorInvalidValue;
     const size_t rows = wide ? (n + kWR - 1) / kWR * kWR : (n + kBP - 1) / kBP * kBP;
 #ifndef PN_DIAG_BF_PACK1
+    if (wide) {  // rows is a multiple of 256
+        hipLaunchKernelGGL((bf16_pack_wide8_kernel<T, false>), dim3((unsigned)(rows * 8 / 256)), dim3(256), 0, s, P, mu, n, rows,
+                           dim, ld, static_cast<uint16_t *>(img), (double *)nullptr, (uint32_t *)nullptr, bad);
+        return hipGetLastError();
+    }
     if (!wide) {  // rows is a multiple of 64: whole blocks of 256 threads = 32 rows
         hipLaunchKernelGGL(bf16_pack_corpus8_kernel<T>, dim3((unsigned)(rows * 8 / 256)), dim3(256), 0, s, P, mu, n, dim, ld,
                            bf16_ks_for(dim, ci), static_cast<uint16_t *>(img), rows, bad, ci ? 1 : 0);
@@ -2600,6 +2729,13 @@ hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size
         hipLaunchKernelGGL(bf16_pack_queries8_kernel<T>, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
                            nq_pad, dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, ci ? 1 : 0,
                            bmax, dmax, Qp, ldq, misc);
+        return hipGetLastError();
+    }
+#endif
+#ifndef PN_DIAG_BF_PACK1
+    if (bf16_is_wide(dim) && !ci && nq_pad % 32 == 0) {  // (nq_pad is a multiple of 256 for wide rows)
+        hipLaunchKernelGGL((bf16_pack_wide8_kernel<T, true>), dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq, nq_pad,
+                           dim, ld, static_cast<uint16_t *>(B), qn, qbad, (uint32_t *)nullptr);
         return hipGetLastError();
     }
 #endif
