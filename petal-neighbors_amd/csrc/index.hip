@@ -893,6 +893,15 @@ template <> struct Ops<float> {
                              const uint32_t *osel = nullptr) {
         return launch_select_exact_f32(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s, osel);
     }
+    static hipError_t select_groups(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t base, uint64_t *io,
+                                    float *dd, size_t gs, const uint32_t *nd, uint32_t no, hipStream_t s) {
+        return launch_select_exact_groups_f32(cb, groups, kp, nq, kout, base, io, dd, gs, nd, no, s);
+    }
+    static hipError_t merge(const uint64_t *pi, const float *pd, int np, size_t is, size_t ds, int nq, int kp, int ko,
+                            uint64_t *io, float *dd, hipStream_t s, const uint32_t *nd, const uint32_t *osel, size_t os,
+                            uint32_t *hc) {
+        return launch_merge_topk_f32(pi, pd, np, is, ds, nq, kp, ko, io, dd, s, nd, osel, os, hc);
+    }
 };
 template <> struct Ops<double> {
     static hipError_t rerank(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
@@ -917,6 +926,15 @@ template <> struct Ops<double> {
                              size_t oo, void *lk, uint32_t *li, const uint32_t *nd, uint32_t no, bool sk, hipStream_t s,
                              const uint32_t *osel = nullptr) {
         return launch_select_exact_f64(cb, nq, kout, base, io, dd, os, oo, lk, li, nd, no, sk, s, osel);
+    }
+    static hipError_t select_groups(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t base, uint64_t *io,
+                                    double *dd, size_t gs, const uint32_t *nd, uint32_t no, hipStream_t s) {
+        return launch_select_exact_groups_f64(cb, groups, kp, nq, kout, base, io, dd, gs, nd, no, s);
+    }
+    static hipError_t merge(const uint64_t *pi, const double *pd, int np, size_t is, size_t ds, int nq, int kp, int ko,
+                            uint64_t *io, double *dd, hipStream_t s, const uint32_t *nd, const uint32_t *osel, size_t os,
+                            uint32_t *hc) {
+        return launch_merge_topk_f64(pi, pd, np, is, ds, nq, kp, ko, io, dd, s, nd, osel, os, hc);
     }
 };
 
@@ -989,42 +1007,42 @@ static int second_tier_exact(const pn_index *ix, Workspace &ws, const T *Qp, siz
     const size_t F = nq < kSecondTierRows ? nq : kSecondTierRows, F_pad = round_up(F, (size_t)256);
     *count_published = false;
     size_t first = 0;
-    if constexpr (sizeof(T) == 4) {  // (f64 indexes: every flagged query takes the rounds below)
     // Few flagged queries are the normal case, and they share ONE 64-query tile: with the usual <= 32 segments that is
-    // <= 32 workgroups for the whole corpus (10M rows: 0.4 s for a single flagged query).  So the first 256 flagged
-    // queries of a chunk are scanned with up to 512 row segments -- every CU busy -- and selected in two levels:
-    // groups of 16 segments to a part each, then the (distance, index) merge of the parts (the shard-merge kernel),
-    // which writes each answer straight to its query's row.
+    // <= 32 workgroups for the whole corpus (10M rows: 0.4 s for a single flagged query; an f64 index's 1M rows: 16 ms,
+    // six of the headline batch's steps).  So the first 256 flagged queries of a chunk are scanned with up to 512 row
+    // segments -- every CU busy -- and selected in two levels: groups of 16 segments to a part each, then the (distance,
+    // index) merge of the parts (the shard-merge kernel), which writes each answer straight to its query's row.
+    // (f32 and, since round 3, f64 indexes: the kernels are templated on the element type.)
+    using KeyT = typename KeyOf<T>::type;
     const size_t by_rows = (ix->n + 4095) / 4096;
     if (kout <= 192 && by_rows >= 16) {
         const size_t Ff = nq < kSecondTierFew ? nq : kSecondTierFew, Ff_pad = kSecondTierFew;
         const int cap = pick_cap(kout);
         size_t groups = by_rows / 16 < 32 ? by_rows / 16 : 32;
-        while (groups > 1 && groups * kout * 12 > 60 * 1024) --groups;  // the merge kernel's LDS
+        while (groups > 1 && groups * kout * (8 + sizeof(KeyT)) > 60 * 1024) --groups;  // the merge kernel's LDS
         const size_t nseg = groups * 16;
         size_t seg_len = round_up((ix->n + nseg - 1) / nseg, (size_t)kRowPad);
         // (a last segment that starts beyond the corpus scans nothing and leaves an empty cell)
         const size_t cells = nseg * Ff_pad, slots = cells * (size_t)cap;
-        PNCHK(ws.w2_keys.ensure(slots * sizeof(uint32_t)));
+        PNCHK(ws.w2_keys.ensure(slots * sizeof(KeyT)));
         PNCHK(ws.w2_idx.ensure(slots * sizeof(uint32_t)));
         PNCHK(ws.w2_cnt.ensure(cells * sizeof(uint32_t)));
-        PNCHK(ws.w2_tau.ensure(cells * sizeof(uint32_t)));
-        PNCHK(ws.w_fparts.ensure(groups * Ff_pad * kout * (sizeof(uint64_t) + sizeof(float))));
+        PNCHK(ws.w2_tau.ensure(cells * sizeof(KeyT)));
+        PNCHK(ws.w_fparts.ensure(groups * Ff_pad * kout * (sizeof(uint64_t) + sizeof(T))));
         uint64_t *p_idx = (uint64_t *)ws.w_fparts.p;
-        float *p_dist = (float *)(p_idx + groups * Ff_pad * kout);
+        T *p_dist = (T *)(p_idx + groups * Ff_pad * kout);
         CandBuf cb{ws.w2_keys.p, (uint32_t *)ws.w2_idx.p, (uint32_t *)ws.w2_cnt.p, ws.w2_tau.p, Ff_pad, (int)nseg, cap};
-        HIPCHK(launch_exact_knn_f32((const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)Ff, ix->ld, (int)kout,
-                                    seg_len, cb, nullptr, nullptr, d_nsel, 0, nullptr, nullptr, s, d_sel));
+        HIPCHK(Ops<T>::knn((const T *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)Ff, ix->ld, (int)kout, seg_len, cb,
+                           nullptr, nullptr, d_nsel, 0, nullptr, nullptr, s, d_sel));
         CandBuf cg = cb;
         cg.nseg = 16;
         // (index_base is added by the group selection; the merge orders the parts' GLOBAL indices)
-        HIPCHK(launch_select_exact_groups_f32(cg, (int)groups, (int)kout, (int)Ff, (int)kout, ix->index_base, p_idx, p_dist,
-                                              Ff_pad * kout, d_nsel, 0, s));
-        HIPCHK(launch_merge_topk_f32(p_idx, p_dist, (int)groups, Ff_pad * kout, Ff_pad * kout, (int)Ff, (int)kout, (int)kout,
-                                     d_idx, d_dist, s, d_nsel, d_sel, out_stride, h_count));
+        HIPCHK(Ops<T>::select_groups(cg, (int)groups, (int)kout, (int)Ff, (int)kout, ix->index_base, p_idx, p_dist,
+                                     Ff_pad * kout, d_nsel, 0, s));
+        HIPCHK(Ops<T>::merge(p_idx, p_dist, (int)groups, Ff_pad * kout, Ff_pad * kout, (int)Ff, (int)kout, (int)kout, d_idx,
+                             d_dist, s, d_nsel, d_sel, out_stride, h_count));
         *count_published = h_count != nullptr;
         first = Ff;
-    }
     }
     for (size_t off = first; off < nq; off += F) {
         const size_t fr = nq - off < F ? nq - off : F;

@@ -116,6 +116,9 @@ hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t
 hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, float *dist_out, size_t out_group_stride,
                                           const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+hipError_t launch_select_exact_groups_f64(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
+                                          uint64_t *idx_out, double *dist_out, size_t out_group_stride,
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).
@@ -154,6 +157,10 @@ hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t 
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
+                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
+hipError_t launch_merge_topk_f64(const uint64_t *idx_parts, const double *dist_parts, int n_parts,
+                                 size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
+                                 uint64_t *idx_out, double *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
                                  const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
 // gather rows sel[off + i] of src into dst row i / scatter result rows i back to query sel[off + i], for
 // i < min(max_rows, *nsel - off): the count stays on the device

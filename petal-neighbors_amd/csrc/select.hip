@@ -197,6 +197,12 @@ hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp,
     return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, kp, (size_t)kout, 0, nullptr, nullptr,
                                       nq_dev, nq_off, false, s, groups, out_group_stride);
 }
+hipError_t launch_select_exact_groups_f64(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
+                                          uint64_t *idx_out, double *dist_out, size_t out_group_stride,
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+    return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, kp, (size_t)kout, 0, nullptr, nullptr,
+                                       nq_dev, nq_off, false, s, groups, out_group_stride);
+}
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
                                    uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, bool signed_keys,
@@ -970,11 +976,12 @@ hipError_t launch_radius_gather(const uint32_t *kept, const uint32_t *nkept, con
 // ---------------------------------------------------------------------------
 // shard merge: parts laid out [part][query][k_part]; (dist, idx) total order.
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restrict__ idx_parts,
-                                                        const float *__restrict__ dist_parts, int n_parts,
+                                                        const T *__restrict__ dist_parts, int n_parts,
                                                         size_t idx_part_stride, size_t dist_part_stride, int nq,
                                                         int k_part, int k_out, uint64_t *__restrict__ idx_out,
-                                                        float *__restrict__ dist_out,
+                                                        T *__restrict__ dist_out,
                                                         const uint32_t *__restrict__ nq_dev,
                                                         const uint32_t *__restrict__ osel, size_t out_stride,
                                                         uint32_t *__restrict__ host_count) {
@@ -987,26 +994,27 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     if (nq_dev && q >= (size_t)*nq_dev) return;  // device-driven query count (second tier, index.hip)
     const size_t qo = osel ? (size_t)osel[q] : q;  // output row
     uint32_t n = (uint32_t)n_parts * (uint32_t)k_part;
+    using KeyT = typename KeyOf<T>::type;
     uint64_t *sidx = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *skey = reinterpret_cast<uint32_t *>(smem + sizeof(uint64_t) * (size_t)n);
+    KeyT *skey = reinterpret_cast<KeyT *>(smem + sizeof(uint64_t) * (size_t)n);
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t part = e / k_part, j = e % k_part;
         const size_t o = q * k_part + j;
         const uint64_t ix = idx_parts[(size_t)part * idx_part_stride + o];
         sidx[e] = ix;
-        skey[e] = (ix == ~0ull) ? KeyOf<float>::kMax : sel_key(dist_parts[(size_t)part * dist_part_stride + o]);
+        skey[e] = (ix == ~0ull) ? KeyOf<T>::kMax : sel_key(dist_parts[(size_t)part * dist_part_stride + o]);
     }
     __syncthreads();
     uint32_t n_valid = 0;
-    for (uint32_t e = lane; e < n; e += 64) n_valid += skey[e] != KeyOf<float>::kMax;
+    for (uint32_t e = lane; e < n; e += 64) n_valid += skey[e] != KeyOf<T>::kMax;
     for (int d = 32; d > 0; d >>= 1) n_valid += __shfl_xor(n_valid, d);
-    n = prune_to_topk<uint32_t, uint64_t>(skey, sidx, n, (uint32_t)k_out, lane);
+    n = prune_to_topk<KeyT, uint64_t>(skey, sidx, n, (uint32_t)k_out, lane);
     __syncthreads();
     for (uint32_t e = lane; e < n; e += 64) {
-        const uint32_t k = skey[e];
+        const KeyT k = skey[e];
         const uint64_t ix = sidx[e];
-        if (k == KeyOf<float>::kMax) continue;
-        const uint32_t r = rank_of<uint32_t, uint64_t>(skey, sidx, n, k, ix);
+        if (k == KeyOf<T>::kMax) continue;
+        const uint32_t r = rank_of<KeyT, uint64_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)k_out) {
             idx_out[qo * out_stride + r] = ix;
             dist_out[qo * out_stride + r] = key_to_dist(k);
@@ -1015,7 +1023,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
     // absent tail (fewer than k_out valid entries over all parts)
     for (uint32_t r = n_valid + lane; r < (uint32_t)k_out; r += 64) {
         idx_out[qo * out_stride + r] = ~0ull;
-        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<float>::kNaN);
+        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<T>::kNaN);
     }
 }
 
@@ -1025,15 +1033,17 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
 // search per (entry, other part), all reads served by L2.  One wave per query; only the first k_out entries of a part
 // can reach the output.  (BallTree::query has no limit on k, src/ball_tree.rs:102-121: the sharded k-NN must not
 // inherit one from a kernel's LDS budget -- 8 GPUs x k = 1000 is 96 KB of (key, index) pairs.)
+template <typename T>
 __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *__restrict__ idx_parts,
-                                                               const float *__restrict__ dist_parts, int n_parts,
+                                                               const T *__restrict__ dist_parts, int n_parts,
                                                                size_t idx_part_stride, size_t dist_part_stride,
                                                                int nq, int k_part, int k_out,
                                                                uint64_t *__restrict__ idx_out,
-                                                               float *__restrict__ dist_out,
+                                                               T *__restrict__ dist_out,
                                                                const uint32_t *__restrict__ nq_dev,
                                                                const uint32_t *__restrict__ osel, size_t out_stride,
                                                                uint32_t *__restrict__ host_count) {
+    using KeyT = typename KeyOf<T>::type;
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
     if (host_count && q == 0 && lane == 0) *host_count = nq_dev ? *nq_dev : 0u;
@@ -1044,7 +1054,7 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
     uint32_t n_valid = 0;
     for (int p = 0; p < n_parts; ++p) {
         const uint64_t *pi = idx_parts + (size_t)p * idx_part_stride + q * kp;
-        const float *pd = dist_parts + (size_t)p * dist_part_stride + q * kp;
+        const T *pd = dist_parts + (size_t)p * dist_part_stride + q * kp;
         // valid entries of this part (absent slots are a suffix): binary search for the first absent one
         uint32_t lo = 0, hi = kp;
         while (lo < hi) {
@@ -1055,17 +1065,17 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
         n_valid += nv;
         for (uint32_t j = (uint32_t)lane; j < (nv < lim ? nv : lim); j += 64) {
             const uint64_t ix = pi[j];
-            const uint32_t key = sel_key(pd[j]);
+            const KeyT key = sel_key(pd[j]);
             uint32_t rank = j;
             for (int o = 0; o < n_parts && rank < ko; ++o) {
                 if (o == p) continue;
                 const uint64_t *oi = idx_parts + (size_t)o * idx_part_stride + q * kp;
-                const float *od = dist_parts + (size_t)o * dist_part_stride + q * kp;
+                const T *od = dist_parts + (size_t)o * dist_part_stride + q * kp;
                 uint32_t a = 0, b = kp;  // first entry of part o that is absent or not below (key, ix)
                 while (a < b) {
                     const uint32_t mid = (a + b) >> 1;
                     const uint64_t mi = oi[mid];
-                    const uint32_t mk = sel_key(od[mid]);
+                    const KeyT mk = sel_key(od[mid]);
                     const bool below = mi != ~0ull && (mk < key || (mk == key && mi < ix));
                     if (below) a = mid + 1; else b = mid;
                 }
@@ -1079,26 +1089,41 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
     }
     for (uint32_t r = n_valid + (uint32_t)lane; r < ko; r += 64) {  // absent tail
         idx_out[qo * out_stride + r] = ~0ull;
-        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<float>::kNaN);
+        dist_out[qo * out_stride + r] = key_to_dist(KeyOf<T>::kNaN);
     }
 }
 
-hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
-                                 size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
-                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev,
-                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
-    const size_t sh = (size_t)n_parts * k_part * 12;
+template <typename T>
+static hipError_t launch_merge_topk(const uint64_t *idx_parts, const T *dist_parts, int n_parts, size_t idx_part_stride,
+                                    size_t dist_part_stride, int nq, int k_part, int k_out, uint64_t *idx_out,
+                                    T *dist_out, hipStream_t s, const uint32_t *nq_dev, const uint32_t *osel,
+                                    size_t out_stride, uint32_t *host_count) {
+    const size_t sh = (size_t)n_parts * k_part * (8 + sizeof(typename KeyOf<T>::type));
     if (out_stride == 0) out_stride = (size_t)k_out;
     if (sh > 64 * 1024) {  // beyond the LDS-resident merge: the rank-by-binary-search merge of sorted parts
-        hipLaunchKernelGGL(merge_sorted_topk_kernel, dim3((unsigned)nq), dim3(64), 0, s, idx_parts, dist_parts, n_parts,
+        hipLaunchKernelGGL(merge_sorted_topk_kernel<T>, dim3((unsigned)nq), dim3(64), 0, s, idx_parts, dist_parts, n_parts,
                            idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel,
                            out_stride, host_count);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
+    hipLaunchKernelGGL(merge_topk_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
                        idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel, out_stride,
                        host_count);
     return hipGetLastError();
+}
+hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
+                                 size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
+                                 uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev,
+                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
+    return launch_merge_topk<float>(idx_parts, dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part, k_out,
+                                    idx_out, dist_out, s, nq_dev, osel, out_stride, host_count);
+}
+hipError_t launch_merge_topk_f64(const uint64_t *idx_parts, const double *dist_parts, int n_parts,
+                                 size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
+                                 uint64_t *idx_out, double *dist_out, hipStream_t s, const uint32_t *nq_dev,
+                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
+    return launch_merge_topk<double>(idx_parts, dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part, k_out,
+                                     idx_out, dist_out, s, nq_dev, osel, out_stride, host_count);
 }
 
 // ---------------------------------------------------------------------------

@@ -105,3 +105,30 @@ def test_f64_query_radius_through_the_bf16_tier(pn, oracle_mod, n, dim, nq):
             for a in range(nq):
                 want = oracle_mod.brute_radius(pts, qs[a], np.float64(r))
                 assert np.array_equal(ids[int(off[a]):int(off[a + 1])], want), (eng, r, a)
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_f64_second_tier_many_segment_path(pn, oracle_mod, k):
+    """A corpus of >= 65 536 rows: the first 256 unproven queries of a call are scanned over up to 512 row segments and
+    selected in two levels (f64 keys, the merge kernel on (f64 distance, index) pairs), the rest in the rounds of the
+    exact engine.  With k' = k a good part of the batch is unproven; with duplicated rows only a handful."""
+    from petal_neighbors_amd import _lib
+    pts, qs = _f64((90000, 32), 61), _f64((700, 32), 62)
+    tree = pn.BallTree.euclidean(pts)
+    tree.set_engine("bf16")
+    tree.set_option(_lib.PN_OPT_FILTER_SLOTS, k)
+    tree.set_option(_lib.PN_OPT_SEGMENTS, 1)
+    idx, dist = tree.query_batch(qs, k)
+    want_i, want_d = oracle_mod.brute_knn(pts, qs, k)
+    assert np.array_equal(idx, want_i)
+    assert dist.tobytes() == want_d.tobytes()
+    assert tree.stats()["fallback_queries"] > 256   # both the many-segment path and the rounds behind it ran
+    pts2 = pts.copy()
+    pts2[1000:1040] = pts2[7]
+    q2 = np.concatenate([pts2[7:8] + 1e-12, qs[:100]])
+    tree2 = pn.BallTree.euclidean(pts2)
+    idx, dist = tree2.query_batch(q2, 10)
+    want_i, want_d = oracle_mod.brute_knn(pts2, q2, 10)
+    assert np.array_equal(idx, want_i)
+    assert dist.tobytes() == want_d.tobytes()
+    assert 1 <= tree2.stats()["fallback_queries"] <= 8
