@@ -156,6 +156,8 @@ int pn_index_create_cosine_f64(const double *points, size_t n_rows, size_t n_col
 /* same, from rows already resident on `device` (row-major, inner stride 1) */
 int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
                                int device, void *stream, pn_index **out);
+int pn_index_create_device_f64(const double *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
+                               int device, void *stream, pn_index **out);
 void pn_index_destroy(pn_index *index);
 int pn_index_info(const pn_index *index, pn_info *out);
 int pn_index_set_option(pn_index *index, int option, int64_t value);

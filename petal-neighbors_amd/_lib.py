@@ -58,6 +58,7 @@ SIGNATURES = {
     "pn_pairwise_device_f32": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp]),
     "pn_pairwise_device_f64": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp]),
     "pn_index_create_device_f32": (_i, [_vp, _sz, _sz, _sz, _i, _vp, C.POINTER(_vp)]),
+    "pn_index_create_device_f64": (_i, [_vp, _sz, _sz, _sz, _i, _vp, C.POINTER(_vp)]),
     "pn_index_destroy": (None, [_vp]),
     "pn_index_info": (_i, [_vp, C.POINTER(PnInfo)]),
     "pn_index_set_option": (_i, [_vp, _i, C.c_int64]),

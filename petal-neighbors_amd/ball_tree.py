@@ -89,10 +89,10 @@ class BallTree:
 
     @classmethod
     def from_device(cls, tensor, stream=None):
-        """Build from a row-major float32 CUDA tensor already in HBM (extension)."""
+        """Build from a row-major float32 or float64 CUDA tensor already in HBM (extension)."""
         import torch
-        if tensor.dtype != torch.float32 or tensor.dim() != 2 or not tensor.is_cuda:
-            raise ValueError("from_device takes a 2-D float32 CUDA tensor")
+        if tensor.dtype not in (torch.float32, torch.float64) or tensor.dim() != 2 or not tensor.is_cuda:
+            raise ValueError("from_device takes a 2-D float32 or float64 CUDA tensor")
         if tensor.shape[1] > 1 and tensor.stride(1) != 1:
             from .errors import NotContiguous
             raise NotContiguous()
@@ -100,10 +100,11 @@ class BallTree:
         dev = tensor.device.index or 0
         h = C.c_void_p(0)
         st = stream if stream is not None else torch.cuda.current_stream(tensor.device).cuda_stream
-        check(_lib.lib().pn_index_create_device_f32(tensor.data_ptr() if n * d else None, n, d,
-                                                    tensor.stride(0) if n > 1 else max(d, 1), dev,
-                                                    C.c_void_p(st), C.byref(h)))
-        return cls(h.value, None, Euclidean(), np.float32, dev)
+        f64 = tensor.dtype == torch.float64
+        create = _lib.lib().pn_index_create_device_f64 if f64 else _lib.lib().pn_index_create_device_f32
+        check(create(tensor.data_ptr() if n * d else None, n, d, tensor.stride(0) if n > 1 else max(d, 1), dev,
+                     C.c_void_p(st), C.byref(h)))
+        return cls(h.value, None, Euclidean(), np.float64 if f64 else np.float32, dev)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -519,8 +519,9 @@ extern "C" int pn_index_create_cosine_f64(const double *points, size_t n_rows, s
     return create_from_host<double>(points, n_rows, n_cols, row_stride, col_stride, device, out, 1);
 }
 
-extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
-                                          int device, void *stream, pn_index **out) {
+template <typename T>
+static int create_from_device(const T *d_points, size_t n_rows, size_t n_cols, size_t row_stride, int device, void *stream,
+                              pn_index **out) {
     PNCHK(validate_create(d_points, n_rows, n_cols, (ptrdiff_t)row_stride, 1, out));
     PNCHK(check_device(device));
     DeviceGuard g(device);
@@ -528,7 +529,7 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
     pn_index *ix = new (std::nothrow) pn_index();
     if (!ix) return fail(PN_ERR_NOMEM, "host allocation failed");
     ix->device = device;
-    ix->elem_bytes = 4;
+    ix->elem_bytes = (int)sizeof(T);
     ix->n = n_rows;
     ix->dim = n_cols;
     ix->ld = pick_ld(n_cols);
@@ -540,7 +541,7 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
         hipStream_t src = (hipStream_t)stream;
         if (hipStreamSynchronize(src) != hipSuccess) rc = fail(PN_ERR_DEVICE, "stream sync failed");
     }
-    if (rc == PN_OK) rc = finish_index<float>(ix, d_points, row_stride, ix->stream);
+    if (rc == PN_OK) rc = finish_index<T>(ix, d_points, row_stride, ix->stream);
     if (rc == PN_OK) {
         pooled_stream_release(device, ix->stream);
         ix->stream = nullptr;
@@ -551,6 +552,14 @@ extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, 
     }
     *out = ix;
     return PN_OK;
+}
+extern "C" int pn_index_create_device_f32(const float *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
+                                          int device, void *stream, pn_index **out) {
+    return create_from_device<float>(d_points, n_rows, n_cols, row_stride, device, stream, out);
+}
+extern "C" int pn_index_create_device_f64(const double *d_points, size_t n_rows, size_t n_cols, size_t row_stride,
+                                          int device, void *stream, pn_index **out) {
+    return create_from_device<double>(d_points, n_rows, n_cols, row_stride, device, stream, out);
 }
 
 extern "C" void pn_index_destroy(pn_index *ix) {

@@ -132,3 +132,20 @@ def test_f64_second_tier_many_segment_path(pn, oracle_mod, k):
     assert np.array_equal(idx, want_i)
     assert dist.tobytes() == want_d.tobytes()
     assert 1 <= tree2.stats()["fallback_queries"] <= 8
+
+
+def test_f64_index_from_rows_already_in_hbm(pn, oracle_mod):
+    """pn_index_create_device_f64: an f64 index built from a device array (a strided view of a wider one) answers like the
+    one built from the host copy."""
+    import torch
+    n, dim, nq, k = 20000, 24, 150, 7
+    wide = torch.from_numpy(_f64((n, dim + 8), 71)).to("cuda:0")
+    view = wide[:, :dim]                       # row stride dim + 8, inner stride 1
+    tree = pn.BallTree.from_device(view)
+    assert tree.dtype == np.float64
+    pts = view.cpu().numpy().copy()
+    qs = _f64((nq, dim), 72)
+    idx, dist = tree.query_batch(qs, k)
+    want_i, want_d = oracle_mod.brute_knn(pts, qs, k)
+    assert np.array_equal(idx, want_i)
+    assert dist.tobytes() == want_d.tobytes()
