@@ -250,6 +250,9 @@ int pn_pairwise_cosine_f64(const double *x, size_t n_rows, size_t n_cols, ptrdif
 int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
                              size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
                              size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device, void *stream);
+int pn_merge_topk_device_f64(const uint64_t *d_idx_parts, const double *d_dist_parts, size_t n_parts,
+                             size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
+                             size_t k_out, uint64_t *d_idx_out, double *d_dist_out, int device, void *stream);
 
 /* ---- tree introspection: BallTree::{num_nodes, children_of, points_of, radius_of, compare_nodes,
  * node_distance_lower_bound} (src/ball_tree.rs:296-353), public in the reference for downstream dual-tree algorithms.
@@ -320,6 +323,13 @@ int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptr
 int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
                                       uint64_t n_total, int rank, int world, const void *comm_id, int device,
                                       void *stream, pn_sharded **out);
+/* the same over an f64 corpus (BallTree<f64, Euclidean>): every shard is an f64 index (pn_index_create_f64: bf16 filter,
+ * f64 re-rank and proof), distances travel and merge as f64 */
+int pn_sharded_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                          ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out);
+int pn_sharded_create_rank_device_f64(const double *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
+                                      uint64_t n_total, int rank, int world, const void *comm_id, int device,
+                                      void *stream, pn_sharded **out);
 void pn_sharded_destroy(pn_sharded *sharded);
 int pn_sharded_info(const pn_sharded *sharded, pn_sharded_info_t *out);
 int pn_sharded_set_option(pn_sharded *sharded, int option, int64_t value); /* forwarded to every local shard */
@@ -330,6 +340,12 @@ int pn_sharded_query_device_f32(const pn_sharded *sharded, const float *d_querie
                                 size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out, void *stream);
 int pn_sharded_query_radius_f32(const pn_sharded *sharded, const float *queries, size_t nq, size_t q_cols,
                                 ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out);
+int pn_sharded_query_f64(const pn_sharded *sharded, const double *queries, size_t nq, size_t q_cols,
+                         ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, double *dist_out);
+int pn_sharded_query_device_f64(const pn_sharded *sharded, const double *d_queries, size_t nq, size_t q_cols,
+                                size_t q_row_stride, size_t k, uint64_t *d_idx_out, double *d_dist_out, void *stream);
+int pn_sharded_query_radius_f64(const pn_sharded *sharded, const double *queries, size_t nq, size_t q_cols,
+                                ptrdiff_t q_row_stride, double radius, uint64_t *offsets, uint64_t **idx_out);
 
 /* ---- diagnostic: the first-tier filter's lower bounds themselves.  bounds_out[q * n_rows + i] = L'(q, p_i)
  * for the first n_rows corpus rows (clamped to n_points), with L' + qnorm_out[q] <= |q - p_i|^2 in real

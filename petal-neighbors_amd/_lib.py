@@ -87,6 +87,7 @@ SIGNATURES = {
     "pn_distance_to_rdistance_f32": (C.c_float, [C.c_float]),
     "pn_distance_to_rdistance_f64": (C.c_double, [C.c_double]),
     "pn_merge_topk_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
+    "pn_merge_topk_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
     "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp, _vp]),
     "pn_tree_num_nodes": (_i, [_vp, _u64p]),
@@ -108,6 +109,11 @@ SIGNATURES = {
     "pn_sharded_query_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
     "pn_sharded_query_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "pn_sharded_query_radius_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_float, _vp, C.POINTER(_vp)]),
+    "pn_sharded_create_f64": (_i, [_vp, _sz, _sz, _ssz, _ssz, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "pn_sharded_create_rank_device_f64": (_i, [_vp, _sz, _sz, _sz, _u64, _i, _i, _vp, _i, _vp, C.POINTER(_vp)]),
+    "pn_sharded_query_f64": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
+    "pn_sharded_query_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "pn_sharded_query_radius_f64": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_double, _vp, C.POINTER(_vp)]),
 }
 
 _lib = None

@@ -1646,10 +1646,11 @@ static int query_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t
 namespace pn {
 // pn_query_device_f32 with a row stride on the outputs (results of query q at [q * out_stride + r], r < min(k, n)):
 // a shard writes straight into the packed buffer the all-gather sends (sharded.hip)
-int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
-                             uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s) {
+template <typename T>
+static int query_device_strided_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                                     uint64_t *d_idx, T *d_dist, size_t out_stride, hipStream_t s) {
     if (!ix) return fail(PN_ERR_INVALID, "index is NULL");
-    if (ix->elem_bytes != 4) return fail(PN_ERR_INVALID, "index element type mismatch");
+    if (ix->elem_bytes != (int)sizeof(T)) return fail(PN_ERR_INVALID, "index element type mismatch");
     const size_t kout = k < ix->n ? k : ix->n;
     if (nq == 0 || kout == 0) return PN_OK;
     if ((!d_q && q_cols) || !d_idx || !d_dist || out_stride < kout) return fail(PN_ERR_INVALID, "bad argument");
@@ -1659,7 +1660,15 @@ int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, si
     WsLease lease(ix);
     lease.s = s;
     PNCHK(ws_acquire(ix, &lease.s, false, &lease.ws));
-    return query_enqueue<float>(ix, *lease.ws, d_q, nq, q_cols, q_stride, kout, d_idx, d_dist, out_stride, s);
+    return query_enqueue<T>(ix, *lease.ws, d_q, nq, q_cols, q_stride, kout, d_idx, d_dist, out_stride, s);
+}
+int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s) {
+    return query_device_strided_impl<float>(ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, out_stride, s);
+}
+int query_device_strided_f64(const pn_index *ix, const double *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, double *d_dist, size_t out_stride, hipStream_t s) {
+    return query_device_strided_impl<double>(ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, out_stride, s);
 }
 }  // namespace pn
 
@@ -2546,10 +2555,10 @@ extern "C" int pn_tree_centroid_of(const pn_index *ix, uint64_t node, void *out_
 // ---------------------------------------------------------------------------
 // shard merge + generator
 // ---------------------------------------------------------------------------
-extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
-                                        size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
-                                        size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device,
-                                        void *stream) {
+template <typename T>
+static int merge_topk_device_impl(const uint64_t *d_idx_parts, const T *d_dist_parts, size_t n_parts, size_t idx_part_stride,
+                                  size_t dist_part_stride, size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
+                                  T *d_dist_out, int device, void *stream) {
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!d_idx_parts || !d_dist_parts || !d_idx_out || !d_dist_out) return fail(PN_ERR_INVALID, "NULL argument");
     if (n_parts == 0 || k_part == 0) return fail(PN_ERR_INVALID, "empty parts");
@@ -2559,9 +2568,23 @@ extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float
     PNCHK(check_device(device));
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
-    HIPCHK(launch_merge_topk_f32(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq,
-                                 (int)k_part, (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream));
+    HIPCHK(Ops<T>::merge(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq, (int)k_part,
+                         (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream, nullptr, nullptr, 0, nullptr));
     return PN_OK;
+}
+extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
+                                        size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
+                                        size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device,
+                                        void *stream) {
+    return merge_topk_device_impl<float>(d_idx_parts, d_dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part,
+                                         k_out, d_idx_out, d_dist_out, device, stream);
+}
+extern "C" int pn_merge_topk_device_f64(const uint64_t *d_idx_parts, const double *d_dist_parts, size_t n_parts,
+                                        size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
+                                        size_t k_out, uint64_t *d_idx_out, double *d_dist_out, int device,
+                                        void *stream) {
+    return merge_topk_device_impl<double>(d_idx_parts, d_dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part,
+                                          k_out, d_idx_out, d_dist_out, device, stream);
 }
 
 extern "C" int pn_fill_uniform_device_f32(float *d_out, uint64_t count, uint64_t seed, uint64_t first_counter,

@@ -324,4 +324,6 @@ namespace pn {
 int set_error(int code, const char *fmt, ...);
 int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
                              uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s);
+int query_device_strided_f64(const pn_index *ix, const double *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
+                             uint64_t *d_idx, double *d_dist, size_t out_stride, hipStream_t s);
 }  // namespace pn

@@ -211,6 +211,7 @@ struct SetGuard {
 }  // namespace
 
 struct pn_sharded {
+    int elem_bytes = 4;  // 4: f32 corpus and queries (the *_f32 entry points), 8: f64
     int profile = 0;  // PN_OPT_PROFILE (also forwarded to the shards)
     uint64_t n_total = 0;
     size_t dim = 0;
@@ -227,7 +228,58 @@ struct pn_sharded {
     mutable std::mutex mu;
 };
 
-static size_t packed_words(size_t nq, size_t kp) { return nq * kp + (nq * kp + 1) / 2; }
+// 8-byte words of one packed part: [nq][kp] indices, then [nq][kp] distances of the handle's element type
+template <typename T>
+static size_t packed_words(size_t nq, size_t kp) {
+    return sizeof(T) == 4 ? nq * kp + (nq * kp + 1) / 2 : 2 * nq * kp;
+}
+// the single-index entry points of either element type (the sharded handle is generic over A like the reference,
+// src/ball_tree.rs:26-30)
+template <typename T> struct ShT;
+template <> struct ShT<float> {
+    static int create(const float *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o) {
+        return pn_index_create_f32(p, n, c, rs, cs, dev, o);
+    }
+    static int create_device(const float *p, size_t n, size_t c, size_t rs, int dev, void *st, pn_index **o) {
+        return pn_index_create_device_f32(p, n, c, rs, dev, st, o);
+    }
+    static int query_strided(const pn_index *ix, const float *q, size_t nq, size_t qc, size_t qs, size_t k, uint64_t *oi,
+                             float *od, size_t os, hipStream_t s) {
+        return query_device_strided_f32(ix, q, nq, qc, qs, k, oi, od, os, s);
+    }
+    static int merge(const uint64_t *pi, const float *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp, size_t ko,
+                     uint64_t *oi, float *od, int dev, void *s) {
+        return pn_merge_topk_device_f32(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s);
+    }
+    static int radius(const pn_index *ix, const float *q, size_t nq, size_t qc, ptrdiff_t qs, float r, uint64_t *off,
+                      uint64_t **out) {
+        return pn_query_radius_f32(ix, q, nq, qc, qs, r, off, out);
+    }
+};
+template <> struct ShT<double> {
+    static int create(const double *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o) {
+        return pn_index_create_f64(p, n, c, rs, cs, dev, o);
+    }
+    static int create_device(const double *p, size_t n, size_t c, size_t rs, int dev, void *st, pn_index **o) {
+        return pn_index_create_device_f64(p, n, c, rs, dev, st, o);
+    }
+    static int query_strided(const pn_index *ix, const double *q, size_t nq, size_t qc, size_t qs, size_t k, uint64_t *oi,
+                             double *od, size_t os, hipStream_t s) {
+        return query_device_strided_f64(ix, q, nq, qc, qs, k, oi, od, os, s);
+    }
+    static int merge(const uint64_t *pi, const double *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp, size_t ko,
+                     uint64_t *oi, double *od, int dev, void *s) {
+        return pn_merge_topk_device_f64(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s);
+    }
+    static int radius(const pn_index *ix, const double *q, size_t nq, size_t qc, ptrdiff_t qs, double r, uint64_t *off,
+                      uint64_t **out) {
+        return pn_query_radius_f64(ix, q, nq, qc, qs, r, off, out);
+    }
+};
+static int check_elem(const pn_sharded *sh, size_t bytes) {
+    if (sh->elem_bytes != (int)bytes) return set_error(PN_ERR_INVALID, "handle element type mismatch (f%d handle)", sh->elem_bytes * 8);
+    return PN_OK;
+}
 
 extern "C" int pn_comm_unique_id(void *id_out) {
     if (!id_out) return set_error(PN_ERR_INVALID, "id_out is NULL");
@@ -280,8 +332,9 @@ static int init_dev_resources(Dev &d) {
 
 // BallTree::new over n_devices row shards, one process.  Validation is the reference's
 // (src/ball_tree.rs:44-49), done on the whole array before anything is split.
-extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
-                                     ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+template <typename T>
+static int sharded_create(const T *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, ptrdiff_t col_stride,
+                          const int *devices, int n_devices, pn_sharded **out) {
     if (!out) return set_error(PN_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_rows == 0) return set_error(PN_ERR_EMPTY, "array is empty");
@@ -299,6 +352,7 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
     SPN(need_rccl());
     pn_sharded *sh = new (std::nothrow) pn_sharded();
     if (!sh) return set_error(PN_ERR_NOMEM, "host allocation failed");
+    sh->elem_bytes = (int)sizeof(T);
     sh->n_total = n_rows;
     sh->dim = n_cols;
     sh->n_shards = n_devices;
@@ -322,8 +376,8 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
         p.hi = std::min<uint64_t>(n_rows, p.lo + sh->per);
         p.dev_slot = (int)(std::find(distinct.begin(), distinct.end(), devices[g]) - distinct.begin());
         if (p.hi > p.lo) {
-            rc = pn_index_create_f32(points + (size_t)p.lo * (size_t)row_stride, (size_t)(p.hi - p.lo), n_cols, row_stride,
-                                     col_stride, devices[g], &p.ix);
+            rc = ShT<T>::create(points + (size_t)p.lo * (size_t)row_stride, (size_t)(p.hi - p.lo), n_cols, row_stride,
+                                col_stride, devices[g], &p.ix);
             if (rc == PN_OK) rc = pn_index_set_option(p.ix, PN_OPT_INDEX_BASE, (int64_t)p.lo);
         }
         sh->parts.push_back(p);
@@ -349,9 +403,10 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
 // One process per GPU: this rank's rows (already on `device`) of an n_total-row corpus.  Shard bounds are the
 // library's: rank r holds rows [r ceil(N/W), min(N, (r+1) ceil(N/W))) -- n_local must be exactly that many (a rank
 // beyond the corpus passes n_local = 0 and still takes part in every exchange).
-extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
-                                                 uint64_t n_total, int rank, int world, const void *comm_id, int device,
-                                                 void *stream, pn_sharded **out) {
+template <typename T>
+static int sharded_create_rank_device(const T *d_rows, size_t n_local, size_t n_cols, size_t row_stride, uint64_t n_total,
+                                      int rank, int world, const void *comm_id, int device, void *stream,
+                                      pn_sharded **out) {
     if (!out) return set_error(PN_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_total == 0) return set_error(PN_ERR_EMPTY, "array is empty");
@@ -369,6 +424,7 @@ extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_l
     SPN(need_rccl());
     pn_sharded *sh = new (std::nothrow) pn_sharded();
     if (!sh) return set_error(PN_ERR_NOMEM, "host allocation failed");
+    sh->elem_bytes = (int)sizeof(T);
     sh->n_total = n_total;
     sh->dim = n_cols;
     sh->n_shards = world;
@@ -384,7 +440,7 @@ extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_l
     p.lo = lo;
     p.hi = hi;
     if (rc == PN_OK && hi > lo) {
-        rc = pn_index_create_device_f32(d_rows, n_local, n_cols, row_stride, device, stream, &p.ix);
+        rc = ShT<T>::create_device(d_rows, n_local, n_cols, row_stride, device, stream, &p.ix);
         if (rc == PN_OK) rc = pn_index_set_option(p.ix, PN_OPT_INDEX_BASE, (int64_t)lo);
     }
     sh->parts.push_back(p);
@@ -404,6 +460,27 @@ extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_l
     }
     *out = sh;
     return PN_OK;
+}
+
+extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                     ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+    return sharded_create<float>(points, n_rows, n_cols, row_stride, col_stride, devices, n_devices, out);
+}
+extern "C" int pn_sharded_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                     ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+    return sharded_create<double>(points, n_rows, n_cols, row_stride, col_stride, devices, n_devices, out);
+}
+extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
+                                                 uint64_t n_total, int rank, int world, const void *comm_id, int device,
+                                                 void *stream, pn_sharded **out) {
+    return sharded_create_rank_device<float>(d_rows, n_local, n_cols, row_stride, n_total, rank, world, comm_id, device,
+                                             stream, out);
+}
+extern "C" int pn_sharded_create_rank_device_f64(const double *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
+                                                 uint64_t n_total, int rank, int world, const void *comm_id, int device,
+                                                 void *stream, pn_sharded **out) {
+    return sharded_create_rank_device<double>(d_rows, n_local, n_cols, row_stride, n_total, rank, world, comm_id, device,
+                                              stream, out);
 }
 
 extern "C" int pn_sharded_info(const pn_sharded *sh, pn_sharded_info_t *out) {
@@ -491,18 +568,20 @@ extern "C" int pn_sharded_get_stats(const pn_sharded *sh, pn_stats *out, int res
 // ---------------------------------------------------------------------------
 // The local half of one chunk on one GPU: every local shard's top-kp, merged when the GPU holds several shards, into
 // the packed buffer `set` with kd slots per query (kd = what one GPU can contribute at most).  Enqueued on `s`.
-static int enqueue_local(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
+template <typename T>
+static int enqueue_local(const pn_sharded *sh, Dev &d, const T *d_q, size_t nq, size_t q_cols, size_t q_stride,
                          size_t k, size_t kp, size_t kd, int set, hipStream_t s) {
-    const size_t words = packed_words(nq, kd), pwords = packed_words(nq, kp);
+    const size_t words = packed_words<T>(nq, kd), pwords = packed_words<T>(nq, kp);
+    constexpr size_t kDW = 8 / sizeof(T);  // distances per 8-byte word
     SPN(d.pack[set].ensure(words * 8));
     const size_t np = d.parts.size();
     uint64_t *oi = (uint64_t *)d.pack[set].p;
-    float *od = reinterpret_cast<float *>(oi + nq * kd);
+    T *od = reinterpret_cast<T *>(oi + nq * kd);
     if (np == 1) {  // straight into the buffer the all-gather sends
         const Part &p = sh->parts[d.parts[0]];
         if (p.hi - p.lo < kd)  // absent slots: index ~0 (and a NaN distance) -- the merge kernel skips them
             SHIP(hipMemsetAsync(oi, 0xFF, words * 8, s));
-        if (p.ix) SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kd ? k : kd, oi, od, kd, s));
+        if (p.ix) SPN(ShT<T>::query_strided(p.ix, d_q, nq, q_cols, q_stride, k < kd ? k : kd, oi, od, kd, s));
         return PN_OK;
     }
     SPN(d.lparts.ensure(np * pwords * 8));
@@ -510,22 +589,23 @@ static int enqueue_local(const pn_sharded *sh, Dev &d, const float *d_q, size_t 
     for (size_t i = 0; i < np; ++i) {
         const Part &p = sh->parts[d.parts[i]];
         uint64_t *pi = stage + i * pwords;
-        float *pd = reinterpret_cast<float *>(pi + nq * kp);
+        T *pd = reinterpret_cast<T *>(pi + nq * kp);
         if (p.hi - p.lo < kp) SHIP(hipMemsetAsync(pi, 0xFF, pwords * 8, s));
-        if (p.ix) SPN(query_device_strided_f32(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
+        if (p.ix) SPN(ShT<T>::query_strided(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
     }
-    return pn_merge_topk_device_f32(stage, reinterpret_cast<const float *>(stage + nq * kp), np, pwords, 2 * pwords, nq, kp,
-                                    kd, oi, od, d.device, s);
+    return ShT<T>::merge(stage, reinterpret_cast<const T *>(stage + nq * kp), np, pwords, kDW * pwords, nq, kp, kd, oi, od,
+                         d.device, s);
 }
 
 // exchange + final merge of one chunk on one GPU, enqueued on `s`: one all-gather of the packed buffer, then the
 // (distance, index) merge of the world's parts into d_idx/d_dist [nq][k_out]
+template <typename T>
 static int enqueue_merge(const pn_sharded *sh, Dev &d, size_t nq, size_t kd, size_t k_out, int set, uint64_t *d_idx,
-                         float *d_dist, hipStream_t s) {
-    const size_t words = packed_words(nq, kd);
+                         T *d_dist, hipStream_t s) {
+    const size_t words = packed_words<T>(nq, kd);
     const uint64_t *g = (const uint64_t *)d.gathered[set].p;
-    return pn_merge_topk_device_f32(g, reinterpret_cast<const float *>(g + nq * kd), (size_t)sh->world, words, 2 * words, nq,
-                                    kd, k_out, d_idx, d_dist, d.device, s);
+    return ShT<T>::merge(g, reinterpret_cast<const T *>(g + nq * kd), (size_t)sh->world, words, (8 / sizeof(T)) * words, nq,
+                         kd, k_out, d_idx, d_dist, d.device, s);
 }
 
 static size_t k_part_of(const pn_sharded *sh, size_t k) {  // slots per query a SHARD fills
@@ -556,13 +636,14 @@ struct DevUse {
 };
 
 // rank mode (or one GPU): queries and results on this process's GPU, everything enqueued on `s`
-static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size_t nq, size_t q_cols, size_t q_stride,
-                            size_t k, uint64_t *d_idx, float *d_dist, hipStream_t s) {
+template <typename T>
+static int query_device_one(const pn_sharded *sh, Dev &d, const T *d_q, size_t nq, size_t q_cols, size_t q_stride,
+                            size_t k, uint64_t *d_idx, T *d_dist, hipStream_t s) {
     const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k), kd = k_dev_of(sh, k);
     SetGuard g(d.device);
     if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
     if (sh->n_shards == 1 && !sh->exchange_always)  // one shard: nothing to exchange, straight into the caller's buffers
-        return query_device_strided_f32(sh->parts[0].ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, k_out, s);
+        return ShT<T>::query_strided(sh->parts[0].ix, d_q, nq, q_cols, q_stride, k, d_idx, d_dist, k_out, s);
     // the merges' LDS-free fallback serves any world x k (select.hip), so nothing here is bounded by k
     const size_t chunk = nq > kShardChunk ? kShardChunk : nq;
     const bool overlapped = nq > chunk;  // two chunks in flight: exchange + merge on the second stream
@@ -581,11 +662,11 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
     size_t n_chunks = 0;
     for (size_t q0 = 0; q0 < nq; q0 += chunk, set ^= 1, ++n_chunks) {
         const size_t nqc = nq - q0 < chunk ? nq - q0 : chunk;
-        const size_t words = packed_words(nqc, kd);
+        const size_t words = packed_words<T>(nqc, kd);
         SPN(d.gathered[set].ensure((size_t)sh->world * words * 8));
         // the packed buffer of this set is free again once the exchange that read it (two chunks ago) has been merged
         if (overlapped && n_chunks >= 2) SHIP(hipStreamWaitEvent(s, d.ev_merged[set], 0));
-        SPN(enqueue_local(sh, d, d_q + q0 * q_stride, nqc, q_cols, q_stride, k, kp, kd, set, s));
+        SPN(enqueue_local<T>(sh, d, d_q + q0 * q_stride, nqc, q_cols, q_stride, k, kp, kd, set, s));
         hipStream_t xs = s;
         if (overlapped) {
             SHIP(hipEventRecord(d.ev_local[set], s));
@@ -594,7 +675,7 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
         }
         if (pslot >= 0) SHIP(hipEventRecord(d.ev_prof[pslot][1], s));
         SNCCL(rccl().AllGather(d.pack[set].p, d.gathered[set].p, words, ncclUint64, d.comm, xs));
-        SPN(enqueue_merge(sh, d, nqc, kd, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
+        SPN(enqueue_merge<T>(sh, d, nqc, kd, k_out, set, d_idx + q0 * k_out, d_dist + q0 * k_out, xs));
         if (pslot >= 0) {
             SHIP(hipEventRecord(d.ev_prof[pslot][2], s));
             d.prof_pending[pslot] = true;
@@ -608,10 +689,11 @@ static int query_device_one(const pn_sharded *sh, Dev &d, const float *d_q, size
     return PN_OK;
 }
 
-extern "C" int pn_sharded_query_device_f32(const pn_sharded *sh, const float *d_queries, size_t nq, size_t q_cols,
-                                           size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out,
-                                           void *stream) {
+template <typename T>
+static int sharded_query_device(const pn_sharded *sh, const T *d_queries, size_t nq, size_t q_cols, size_t q_row_stride,
+                                size_t k, uint64_t *d_idx_out, T *d_dist_out, void *stream) {
     if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    SPN(check_elem(sh, sizeof(T)));
     const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total);
     if (nq == 0 || k_out == 0) return PN_OK;  // k == 0 -> empty result (src/ball_tree.rs:106-108)
     if (!d_queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
@@ -620,14 +702,26 @@ extern "C" int pn_sharded_query_device_f32(const pn_sharded *sh, const float *d_
         return set_error(PN_ERR_UNSUPPORTED, "device-resident queries need a handle that drives ONE GPU (one process per "
                                              "GPU, or all shards on one device); use pn_sharded_query_f32");
     std::lock_guard<std::mutex> lk(sh->mu);
-    return query_device_one(sh, sh->devs[0], d_queries, nq, q_cols, q_row_stride, k, d_idx_out,
-                            d_dist_out, (hipStream_t)stream);
+    return query_device_one<T>(sh, sh->devs[0], d_queries, nq, q_cols, q_row_stride, k, d_idx_out,
+                               d_dist_out, (hipStream_t)stream);
+}
+extern "C" int pn_sharded_query_device_f32(const pn_sharded *sh, const float *d_queries, size_t nq, size_t q_cols,
+                                           size_t q_row_stride, size_t k, uint64_t *d_idx_out, float *d_dist_out,
+                                           void *stream) {
+    return sharded_query_device<float>(sh, d_queries, nq, q_cols, q_row_stride, k, d_idx_out, d_dist_out, stream);
+}
+extern "C" int pn_sharded_query_device_f64(const pn_sharded *sh, const double *d_queries, size_t nq, size_t q_cols,
+                                           size_t q_row_stride, size_t k, uint64_t *d_idx_out, double *d_dist_out,
+                                           void *stream) {
+    return sharded_query_device<double>(sh, d_queries, nq, q_cols, q_row_stride, k, d_idx_out, d_dist_out, stream);
 }
 
 // Host entry point: BallTree::query over the sharded corpus for a batch of host queries.
-extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
-                                    ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out) {
+template <typename T>
+static int sharded_query_host(const pn_sharded *sh, const T *queries, size_t nq, size_t q_cols, ptrdiff_t q_row_stride,
+                              size_t k, uint64_t *idx_out, T *dist_out) {
     if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    SPN(check_elem(sh, sizeof(T)));
     const size_t k_out = (size_t)std::min<uint64_t>(k, sh->n_total), kp = k_part_of(sh, k), kd = k_dev_of(sh, k);
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
@@ -640,31 +734,31 @@ extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, 
     for (Dev &d : devs) {
         SetGuard g(d.device);
         if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
-        SPN(d.q.ensure(nq * qc * sizeof(float)));
+        SPN(d.q.ensure(nq * qc * sizeof(T)));
         if (q_cols) {
             if (nq == 1 || (size_t)q_row_stride == q_cols)
-                SHIP(hipMemcpyAsync(d.q.p, queries, nq * q_cols * sizeof(float), hipMemcpyHostToDevice, d.stream));
+                SHIP(hipMemcpyAsync(d.q.p, queries, nq * q_cols * sizeof(T), hipMemcpyHostToDevice, d.stream));
             else
-                SHIP(hipMemcpy2DAsync(d.q.p, q_cols * sizeof(float), queries, (size_t)q_row_stride * sizeof(float),
-                                      q_cols * sizeof(float), nq, hipMemcpyHostToDevice, d.stream));
+                SHIP(hipMemcpy2DAsync(d.q.p, q_cols * sizeof(T), queries, (size_t)q_row_stride * sizeof(T),
+                                      q_cols * sizeof(T), nq, hipMemcpyHostToDevice, d.stream));
         }
     }
     Dev &d0 = devs[0];
     {
         SetGuard g(d0.device);
         SPN(d0.out_idx.ensure(nq * k_out * sizeof(uint64_t)));
-        SPN(d0.out_dist.ensure(nq * k_out * sizeof(float)));
+        SPN(d0.out_dist.ensure(nq * k_out * sizeof(T)));
     }
     if (devs.size() == 1) {
-        SPN(query_device_one(sh, d0, (const float *)d0.q.p, nq, q_cols, qc, k, (uint64_t *)d0.out_idx.p,
-                             (float *)d0.out_dist.p, d0.stream));
+        SPN(query_device_one<T>(sh, d0, (const T *)d0.q.p, nq, q_cols, qc, k, (uint64_t *)d0.out_idx.p,
+                                (T *)d0.out_dist.p, d0.stream));
     } else {
         // one process, several GPUs: local work on every GPU, ONE grouped all-gather, merge on the first GPU
-        const size_t words = packed_words(nq, kd);
+        const size_t words = packed_words<T>(nq, kd);
         for (Dev &d : devs) {
             SetGuard g(d.device);
             SPN(d.gathered[0].ensure((size_t)sh->world * words * 8));
-            SPN(enqueue_local(sh, d, (const float *)d.q.p, nq, q_cols, qc, k, kp, kd, 0, d.stream));
+            SPN(enqueue_local<T>(sh, d, (const T *)d.q.p, nq, q_cols, qc, k, kp, kd, 0, d.stream));
         }
         SNCCL(rccl().GroupStart());
         for (Dev &d : devs) {
@@ -676,18 +770,26 @@ extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, 
         }
         SNCCL(rccl().GroupEnd());
         SetGuard g(d0.device);
-        SPN(enqueue_merge(sh, d0, nq, kd, k_out, 0, (uint64_t *)d0.out_idx.p, (float *)d0.out_dist.p, d0.stream));
+        SPN(enqueue_merge<T>(sh, d0, nq, kd, k_out, 0, (uint64_t *)d0.out_idx.p, (T *)d0.out_dist.p, d0.stream));
     }
     {
         SetGuard g(d0.device);
         SHIP(hipMemcpyAsync(idx_out, d0.out_idx.p, nq * k_out * sizeof(uint64_t), hipMemcpyDeviceToHost, d0.stream));
-        SHIP(hipMemcpyAsync(dist_out, d0.out_dist.p, nq * k_out * sizeof(float), hipMemcpyDeviceToHost, d0.stream));
+        SHIP(hipMemcpyAsync(dist_out, d0.out_dist.p, nq * k_out * sizeof(T), hipMemcpyDeviceToHost, d0.stream));
     }
     for (Dev &d : devs) {  // every GPU has left the collective before the call returns
         SetGuard g(d.device);
         SHIP(hipStreamSynchronize(d.stream));
     }
     return PN_OK;
+}
+extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
+                                    ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, float *dist_out) {
+    return sharded_query_host<float>(sh, queries, nq, q_cols, q_row_stride, k, idx_out, dist_out);
+}
+extern "C" int pn_sharded_query_f64(const pn_sharded *sh, const double *queries, size_t nq, size_t q_cols,
+                                    ptrdiff_t q_row_stride, size_t k, uint64_t *idx_out, double *dist_out) {
+    return sharded_query_host<double>(sh, queries, nq, q_cols, q_row_stride, k, idx_out, dist_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -697,9 +799,11 @@ extern "C" int pn_sharded_query_f32(const pn_sharded *sh, const float *queries, 
 // shard -- shards are ascending row ranges, so the concatenation is ascending.  Local shards answer through
 // pn_query_radius_f32; with one process per GPU the variable-length lists travel by two all-gathers (counts, then the
 // lists padded to the longest) and are spliced on the host.
-extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
-                                           ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out) {
+template <typename T>
+static int sharded_query_radius(const pn_sharded *sh, const T *queries, size_t nq, size_t q_cols, ptrdiff_t q_row_stride,
+                                T radius, uint64_t *offsets, uint64_t **idx_out) {
     if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    SPN(check_elem(sh, sizeof(T)));
     if (!offsets || !idx_out) return set_error(PN_ERR_INVALID, "output pointer is NULL");
     *idx_out = nullptr;
     offsets[0] = 0;
@@ -717,7 +821,7 @@ extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *qu
     } free_lists{lists};
     for (size_t i = 0; i < np; ++i)
         if (sh->parts[i].ix)
-            SPN(pn_query_radius_f32(sh->parts[i].ix, queries, nq, q_cols, q_row_stride, radius, offs[i].data(), &lists[i]));
+            SPN(ShT<T>::radius(sh->parts[i].ix, queries, nq, q_cols, q_row_stride, radius, offs[i].data(), &lists[i]));
     // local splice: per query, local shards in order
     std::vector<uint64_t> l_cnt(nq, 0);
     for (size_t i = 0; i < np; ++i)
@@ -790,4 +894,12 @@ extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *qu
     offsets[nq] = w;
     *idx_out = res;
     return PN_OK;
+}
+extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
+                                           ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out) {
+    return sharded_query_radius<float>(sh, queries, nq, q_cols, q_row_stride, radius, offsets, idx_out);
+}
+extern "C" int pn_sharded_query_radius_f64(const pn_sharded *sh, const double *queries, size_t nq, size_t q_cols,
+                                           ptrdiff_t q_row_stride, double radius, uint64_t *offsets, uint64_t **idx_out) {
+    return sharded_query_radius<double>(sh, queries, nq, q_cols, q_row_stride, radius, offsets, idx_out);
 }

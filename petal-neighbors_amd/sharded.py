@@ -36,11 +36,13 @@ def shard_bounds(n: int, world: int, rank: int):
 class ShardedIndex:
     """A ``pn_sharded`` handle (include/petal_mi355x.h): row shards + RCCL exchange behind the ABI."""
 
-    def __init__(self, handle, keep=None):
+    def __init__(self, handle, keep=None, dtype=np.float32):
         from . import _lib
         from .errors import check
         self._h = C.c_void_p(handle)
         self._keep = keep
+        self.dtype = np.dtype(dtype)   # float32 or float64: the element type of corpus, queries and distances
+        self._sfx = "f64" if self.dtype == np.float64 else "f32"
         info = _lib.PnShardedInfo()
         check(_lib.lib().pn_sharded_info(self._h, C.byref(info)))
         self.n, self.dim = int(info.n_points), int(info.dim)
@@ -55,7 +57,7 @@ class ShardedIndex:
         from . import _lib
         from .errors import check
         a = np.asarray(points)
-        if a.dtype != np.float32:
+        if a.dtype not in (np.float32, np.float64):   # (an f64 array gives an f64 handle, like BallTree::new is generic over A)
             a = a.astype(np.float32)
         if a.ndim != 2:
             raise ValueError("points must be a 2-D array (Ix2)")
@@ -64,9 +66,9 @@ class ShardedIndex:
         rs, cs = (a.strides[0] // item, a.strides[1] // item) if n and d else (max(d, 1), 1)
         devs = (C.c_int * len(devices))(*[int(x) for x in devices])
         h = C.c_void_p(0)
-        check(_lib.lib().pn_sharded_create_f32(a.ctypes.data if a.size else None, n, d, rs, cs if d > 1 else 1, devs,
-                                               len(devices), C.byref(h)))
-        return cls(h.value, keep=a)
+        create = _lib.lib().pn_sharded_create_f64 if a.dtype == np.float64 else _lib.lib().pn_sharded_create_f32
+        check(create(a.ctypes.data if a.size else None, n, d, rs, cs if d > 1 else 1, devs, len(devices), C.byref(h)))
+        return cls(h.value, keep=a, dtype=a.dtype)
 
     @staticmethod
     def unique_id() -> bytes:
@@ -84,16 +86,17 @@ class ShardedIndex:
         from .errors import check
         h = C.c_void_p(0)
         if rows is not None and rows.numel():
-            if rows.dtype != torch.float32 or rows.dim() != 2 or not rows.is_cuda or (rows.shape[1] > 1 and rows.stride(1) != 1):
-                raise ValueError("rows must be a row-major 2-D float32 CUDA tensor")
+            if rows.dtype not in (torch.float32, torch.float64) or rows.dim() != 2 or not rows.is_cuda or (rows.shape[1] > 1 and rows.stride(1) != 1):
+                raise ValueError("rows must be a row-major 2-D float32 or float64 CUDA tensor")
             ptr, nl, d, ld = rows.data_ptr(), rows.shape[0], rows.shape[1], (rows.stride(0) if rows.shape[0] > 1 else max(rows.shape[1], 1))
             st = stream if stream is not None else torch.cuda.current_stream(rows.device).cuda_stream
         else:
             ptr, nl, d, ld, st = None, 0, (rows.shape[1] if rows is not None else 0), 1, 0
         idb = C.create_string_buffer(bytes(comm_id), _lib.PN_COMM_ID_BYTES)
-        check(_lib.lib().pn_sharded_create_rank_device_f32(ptr, nl, d, ld, int(n_total), int(rank), int(world), idb,
-                                                           int(device), C.c_void_p(st), C.byref(h)))
-        return cls(h.value)
+        f64 = rows is not None and rows.dtype == torch.float64
+        create = _lib.lib().pn_sharded_create_rank_device_f64 if f64 else _lib.lib().pn_sharded_create_rank_device_f32
+        check(create(ptr, nl, d, ld, int(n_total), int(rank), int(world), idb, int(device), C.c_void_p(st), C.byref(h)))
+        return cls(h.value, dtype=np.float64 if f64 else np.float32)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -129,23 +132,23 @@ class ShardedIndex:
         return self.n
 
     def query_batch(self, queries, k: int):
-        """host queries (nq, d) -> (idx uint64, dist float32) of shape (nq, min(k, n))"""
+        """host queries (nq, d) -> (idx uint64, dist of the handle's dtype) of shape (nq, min(k, n))"""
         from . import _lib
         from .errors import check
-        a = np.ascontiguousarray(queries, dtype=np.float32)
+        a = np.ascontiguousarray(queries, dtype=self.dtype)
         if a.ndim != 2:
             raise ValueError("queries must be 2-D")
         nq, qc = a.shape
         kout = min(int(k), self.n)
         idx = np.empty((nq, kout), dtype=np.uint64)
-        dist = np.empty((nq, kout), dtype=np.float32)
+        dist = np.empty((nq, kout), dtype=self.dtype)
         if nq and kout:
-            check(_lib.lib().pn_sharded_query_f32(self._h, a.ctypes.data, nq, qc, max(qc, 1), int(k), idx.ctypes.data,
-                                                  dist.ctypes.data))
+            check(getattr(_lib.lib(), "pn_sharded_query_" + self._sfx)(self._h, a.ctypes.data, nq, qc, max(qc, 1), int(k),
+                                                                      idx.ctypes.data, dist.ctypes.data))
         return idx, dist
 
     def query(self, point, k: int):
-        i, d = self.query_batch(np.asarray(point, dtype=np.float32).reshape(1, -1), k)
+        i, d = self.query_batch(np.asarray(point, dtype=self.dtype).reshape(1, -1), k)
         return i[0], d[0]
 
     def query_device(self, queries, k: int, out_idx=None, out_dist=None, stream=None):
@@ -153,8 +156,9 @@ class ShardedIndex:
         import torch
         from . import _lib
         from .errors import check
-        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_cuda:
-            raise ValueError("queries must be a 2-D float32 CUDA tensor")
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        if queries.dtype != tdt or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a 2-D CUDA tensor of the handle's dtype (%s)" % self.dtype)
         if queries.shape[1] > 1 and queries.stride(1) != 1:
             queries = queries.contiguous()
         nq, qc = queries.shape
@@ -162,24 +166,25 @@ class ShardedIndex:
         if out_idx is None:
             out_idx = torch.empty((nq, kout), dtype=torch.int64, device=queries.device)
         if out_dist is None:
-            out_dist = torch.empty((nq, kout), dtype=torch.float32, device=queries.device)
+            out_dist = torch.empty((nq, kout), dtype=tdt, device=queries.device)
         if nq and kout:
             st = stream if stream is not None else torch.cuda.current_stream(queries.device).cuda_stream
-            check(_lib.lib().pn_sharded_query_device_f32(self._h, queries.data_ptr(), nq, qc,
-                                                         queries.stride(0) if nq > 1 else max(qc, 1), int(k),
-                                                         out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
+            check(getattr(_lib.lib(), "pn_sharded_query_device_" + self._sfx)(
+                self._h, queries.data_ptr(), nq, qc, queries.stride(0) if nq > 1 else max(qc, 1), int(k),
+                out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
         return out_idx, out_dist
 
     def query_radius_batch(self, queries, distance):
         """CSR (offsets[nq+1], indices) of ``{ i : dist(q, p_i) < distance }`` over all shards, ascending per query."""
         from . import _lib
         from .errors import check
-        a = np.ascontiguousarray(queries, dtype=np.float32)
+        a = np.ascontiguousarray(queries, dtype=self.dtype)
         nq, qc = a.shape
         offsets = np.zeros(nq + 1, dtype=np.uint64)
         out = C.c_void_p(0)
-        check(_lib.lib().pn_sharded_query_radius_f32(self._h, a.ctypes.data, nq, qc, max(qc, 1), C.c_float(distance),
-                                                     offsets.ctypes.data, C.byref(out)))
+        r = C.c_double(distance) if self.dtype == np.float64 else C.c_float(distance)
+        check(getattr(_lib.lib(), "pn_sharded_query_radius_" + self._sfx)(self._h, a.ctypes.data, nq, qc, max(qc, 1), r,
+                                                                         offsets.ctypes.data, C.byref(out)))
         total = int(offsets[-1])
         try:
             idx = (np.frombuffer((C.c_uint64 * total).from_address(out.value), dtype=np.uint64).copy()

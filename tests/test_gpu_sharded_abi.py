@@ -271,3 +271,66 @@ def test_two_host_threads_share_one_handle(pn, oracle_mod):
         t.join()
     assert not errs, errs
     assert tree.stats()["queries"] == 4 * 6 * 256
+
+
+def _f64(shape, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random(shape)  # 53 random bits: values no f32 represents
+
+
+@pytest.mark.parametrize("shards", [1, 3, 8])
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 64, 150, 10), (900, 16, 40, 35), (37, 3, 9, 5)])
+def test_f64_virtual_shards_through_the_abi(pn, oracle_mod, shards, n, dim, nq, k):
+    """The sharded handle is generic over the element type like BallTree<A, M> (src/ball_tree.rs:26-30): an f64 corpus
+    gives f64 shards (bf16 filter, f64 re-rank), distances travel and merge as f64 -- results equal the oracle's f64
+    brute force bit for bit, k-NN and radius, host and device entry points."""
+    import torch
+    from petal_neighbors_amd import _lib
+    pts = _f64((n, dim), 277 + n)
+    if n > 100:
+        pts[n - 1] = pts[0]  # duplicate across shards: the tie is broken by the GLOBAL index
+    h = min(3, n)
+    qs = np.concatenate([pts[:h], _f64((nq - h, dim), 278 + n)])
+    sh = pn.ShardedIndex.from_host(pts, [0] * shards)
+    assert sh.dtype == np.float64 and (sh.n, sh.dim, sh.n_shards, sh.world) == (n, dim, shards, 1)
+    sh.set_option(_lib.PN_OPT_EXCHANGE_ALWAYS, 1)
+    want_i, want_d = oracle_mod.brute_knn(pts, qs, k)
+    assert want_d.dtype == np.float64
+    gi, gd = sh.query_batch(qs, k)
+    assert gd.dtype == np.float64 and _same(gi, gd, want_i, want_d)
+    if n <= 5000:  # k beyond a shard's rows (absent slots in the packed buffers), and beyond the corpus
+        for kk in (n // shards + 3, n + 5):
+            wi, wd = oracle_mod.brute_knn(pts, qs, kk)
+            gi, gd = sh.query_batch(qs, kk)
+            assert _same(gi, gd, wi, wd), kk
+    # device entry point (one process drives one GPU)
+    qd = torch.from_numpy(qs).to("cuda:0")
+    di, dd = sh.query_device(qd, k)
+    torch.cuda.synchronize()
+    assert dd.dtype == torch.float64 and _same(di.cpu().numpy(), dd.cpu().numpy(), want_i, want_d)
+    with pytest.raises(Exception):
+        sh.query_device(qd.float(), k)   # an f32 batch on an f64 handle
+    # radius
+    _, d = oracle_mod.brute_knn(pts, qs, min(4, n))
+    r = float(np.median(d[:, -1]))
+    off, ids = sh.query_radius_batch(qs, r)
+    assert off[0] == 0 and off[-1] == len(ids)
+    for a in range(nq):
+        assert np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle_mod.brute_radius(pts, qs[a], np.float64(r))), a
+    sh.close()
+
+
+def test_f64_rank_entry_at_world_size_one(pn, oracle_mod):
+    """pn_sharded_create_rank_device_f64: one process per GPU at world size 1, f64 rows already in HBM, exchange forced."""
+    import torch
+    from petal_neighbors_amd import _lib
+    n, dim, nq, k = 9000, 48, 100, 8
+    pts, qs = _f64((n, dim), 91), _f64((nq, dim), 92)
+    rows = torch.from_numpy(pts).to("cuda:0")
+    sh = pn.ShardedIndex.from_rank_device(rows, n, 0, 1, pn.ShardedIndex.unique_id(), 0)
+    assert sh.dtype == np.float64
+    sh.set_option(_lib.PN_OPT_EXCHANGE_ALWAYS, 1)
+    gi, gd = sh.query_device(torch.from_numpy(qs).to("cuda:0"), k)
+    torch.cuda.synchronize()
+    assert _same(gi.cpu().numpy(), gd.cpu().numpy(), *oracle_mod.brute_knn(pts, qs, k))
+    sh.close()
