@@ -76,4 +76,13 @@ extern "C" {
     pub fn pn_sharded_query_radius_f32(sharded: *const pn_sharded, queries: *const f32, nq: usize, q_cols: usize,
                                        q_row_stride: isize, radius: f32, offsets: *mut u64,
                                        idx_out: *mut *mut u64) -> c_int;
+    // the same over an f64 corpus
+    pub fn pn_sharded_create_f64(points: *const f64, n_rows: usize, n_cols: usize, row_stride: isize,
+                                 col_stride: isize, devices: *const c_int, n_devices: c_int,
+                                 out: *mut *mut pn_sharded) -> c_int;
+    pub fn pn_sharded_query_f64(sharded: *const pn_sharded, queries: *const f64, nq: usize, q_cols: usize,
+                                q_row_stride: isize, k: usize, idx_out: *mut u64, dist_out: *mut f64) -> c_int;
+    pub fn pn_sharded_query_radius_f64(sharded: *const pn_sharded, queries: *const f64, nq: usize, q_cols: usize,
+                                       q_row_stride: isize, radius: f64, offsets: *mut u64,
+                                       idx_out: *mut *mut u64) -> c_int;
 }

@@ -226,40 +226,63 @@ class VantagePointTree {
     std::pair<size_t, A> query_nearest(const A *point, size_t len) const { return tree_.query_nearest(point, len); }
 };
 
-// Row-sharded BallTree<f32> over several GPUs driven by this process (petal_mi355x.h, pn_sharded_*): shard g of
+// Row-sharded BallTree<A, Euclidean> over several GPUs driven by this process (petal_mi355x.h, pn_sharded_*): shard g of
 // devices.size() lives on devices[g]; one RCCL all-gather per query batch; answers equal the single-index answers.
-class ShardedBallTree {
+// A = float | double (the reference is generic over A, src/ball_tree.rs:26-30).
+namespace detail {
+inline int sh_create(const float *p, size_t r, size_t c, ptrdiff_t rs, ptrdiff_t cs, const int *d, int n, pn_sharded **o) {
+    return pn_sharded_create_f32(p, r, c, rs, cs, d, n, o);
+}
+inline int sh_create(const double *p, size_t r, size_t c, ptrdiff_t rs, ptrdiff_t cs, const int *d, int n, pn_sharded **o) {
+    return pn_sharded_create_f64(p, r, c, rs, cs, d, n, o);
+}
+inline int sh_query(const pn_sharded *h, const float *q, size_t nq, size_t len, size_t k, uint64_t *i, float *d) {
+    return pn_sharded_query_f32(h, q, nq, len, (ptrdiff_t)len, k, i, d);
+}
+inline int sh_query(const pn_sharded *h, const double *q, size_t nq, size_t len, size_t k, uint64_t *i, double *d) {
+    return pn_sharded_query_f64(h, q, nq, len, (ptrdiff_t)len, k, i, d);
+}
+inline int sh_radius(const pn_sharded *h, const float *q, size_t len, float r, uint64_t *off, uint64_t **out) {
+    return pn_sharded_query_radius_f32(h, q, 1, len, (ptrdiff_t)len, r, off, out);
+}
+inline int sh_radius(const pn_sharded *h, const double *q, size_t len, double r, uint64_t *off, uint64_t **out) {
+    return pn_sharded_query_radius_f64(h, q, 1, len, (ptrdiff_t)len, r, off, out);
+}
+}  // namespace detail
+template <typename A>
+class ShardedBallTreeT {
     pn_sharded *h_ = nullptr;
     size_t n_ = 0;
 
   public:
-    ShardedBallTree(const float *points, size_t rows, size_t cols, const std::vector<int> &devices,
-                    ptrdiff_t row_stride = -1, ptrdiff_t col_stride = 1)
+    ShardedBallTreeT(const A *points, size_t rows, size_t cols, const std::vector<int> &devices,
+                     ptrdiff_t row_stride = -1, ptrdiff_t col_stride = 1)
         : n_(rows) {
         if (row_stride < 0) row_stride = (ptrdiff_t)cols;
-        check(pn_sharded_create_f32(points, rows, cols, row_stride, col_stride, devices.data(), (int)devices.size(), &h_));
+        check(detail::sh_create(points, rows, cols, row_stride, col_stride, devices.data(), (int)devices.size(), &h_));
     }
-    ShardedBallTree(const ShardedBallTree &) = delete;
-    ~ShardedBallTree() { pn_sharded_destroy(h_); }
+    ShardedBallTreeT(const ShardedBallTreeT &) = delete;
+    ~ShardedBallTreeT() { pn_sharded_destroy(h_); }
     size_t num_points() const { return n_; }
-    std::pair<std::vector<size_t>, std::vector<float>> query(const float *point, size_t len, size_t k) const {
+    std::pair<std::vector<size_t>, std::vector<A>> query(const A *point, size_t len, size_t k) const {
         const size_t kout = k < n_ ? k : n_;
         std::vector<uint64_t> idx(kout);
-        std::vector<float> dist(kout);
-        check(pn_sharded_query_f32(h_, point, 1, len, (ptrdiff_t)len, k, idx.data(), dist.data()));
+        std::vector<A> dist(kout);
+        check(detail::sh_query(h_, point, 1, len, k, idx.data(), dist.data()));
         return {std::vector<size_t>(idx.begin(), idx.end()), std::move(dist)};
     }
-    void query_batch(const float *queries, size_t nq, size_t len, size_t k, uint64_t *idx_out, float *dist_out) const {
-        check(pn_sharded_query_f32(h_, queries, nq, len, (ptrdiff_t)len, k, idx_out, dist_out));
+    void query_batch(const A *queries, size_t nq, size_t len, size_t k, uint64_t *idx_out, A *dist_out) const {
+        check(detail::sh_query(h_, queries, nq, len, k, idx_out, dist_out));
     }
-    std::vector<size_t> query_radius(const float *point, size_t len, float distance) const {
+    std::vector<size_t> query_radius(const A *point, size_t len, A distance) const {
         uint64_t off[2] = {0, 0};
         uint64_t *out = nullptr;
-        check(pn_sharded_query_radius_f32(h_, point, 1, len, (ptrdiff_t)len, distance, off, &out));
+        check(detail::sh_radius(h_, point, len, distance, off, &out));
         std::vector<size_t> v(out, out + off[1]);
         pn_free(out);
         return v;
     }
 };
+using ShardedBallTree = ShardedBallTreeT<float>;
 
 }  // namespace petal

@@ -110,6 +110,18 @@ int main(int argc, char **argv) {
         EXPECT(a1.first == a2.first && a1.second == a2.second);
         EXPECT(sh.query_radius(qs.data(), 8, a2.second[3]) == one.query_radius(qs.data(), 8, a2.second[3]));
     }
+    {   // the same over an f64 corpus (BallTree<f64, Euclidean>)
+        std::vector<double> big(3000 * 8), qs(8);
+        unsigned long long s = 98765ull;
+        for (double &v : big) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (double)(s >> 11) * (1.0 / 9007199254740992.0); }
+        for (double &v : qs) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (double)(s >> 11) * (1.0 / 9007199254740992.0); }
+        petal::ShardedBallTreeT<double> sh(big.data(), 3000, 8, {0, 0, 0});
+        petal::BallTree<double> one = petal::BallTree<double>::euclidean(big.data(), 3000, 8);
+        auto a1 = sh.query(qs.data(), 8, 7);
+        auto a2 = one.query(qs.data(), 8, 7);
+        EXPECT(a1.first == a2.first && a1.second == a2.second);
+        EXPECT(sh.query_radius(qs.data(), 8, a2.second[3]) == one.query_radius(qs.data(), 8, a2.second[3]));
+    }
     std::printf("%s\n", fails ? "FAILED" : "ok");
     return fails;
 }
