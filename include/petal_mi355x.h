@@ -330,6 +330,12 @@ int pn_sharded_create_f64(const double *points, size_t n_rows, size_t n_cols, pt
 int pn_sharded_create_rank_device_f64(const double *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
                                       uint64_t n_total, int rank, int world, const void *comm_id, int device,
                                       void *stream, pn_sharded **out);
+/* BallTree::new(points, Cosine) over row shards driven by THIS process (every shard a pn_index_create_cosine_* index;
+ * queries through pn_sharded_query_* / pn_sharded_query_radius_* of the same element type) */
+int pn_sharded_create_cosine_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                 ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out);
+int pn_sharded_create_cosine_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                 ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out);
 void pn_sharded_destroy(pn_sharded *sharded);
 int pn_sharded_info(const pn_sharded *sharded, pn_sharded_info_t *out);
 int pn_sharded_set_option(pn_sharded *sharded, int option, int64_t value); /* forwarded to every local shard */

@@ -110,6 +110,8 @@ SIGNATURES = {
     "pn_sharded_query_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "pn_sharded_query_radius_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_float, _vp, C.POINTER(_vp)]),
     "pn_sharded_create_f64": (_i, [_vp, _sz, _sz, _ssz, _ssz, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "pn_sharded_create_cosine_f32": (_i, [_vp, _sz, _sz, _ssz, _ssz, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "pn_sharded_create_cosine_f64": (_i, [_vp, _sz, _sz, _ssz, _ssz, C.POINTER(_i), _i, C.POINTER(_vp)]),
     "pn_sharded_create_rank_device_f64": (_i, [_vp, _sz, _sz, _sz, _u64, _i, _i, _vp, _i, _vp, C.POINTER(_vp)]),
     "pn_sharded_query_f64": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp]),
     "pn_sharded_query_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),

@@ -2558,7 +2558,7 @@ extern "C" int pn_tree_centroid_of(const pn_index *ix, uint64_t node, void *out_
 template <typename T>
 static int merge_topk_device_impl(const uint64_t *d_idx_parts, const T *d_dist_parts, size_t n_parts, size_t idx_part_stride,
                                   size_t dist_part_stride, size_t nq, size_t k_part, size_t k_out, uint64_t *d_idx_out,
-                                  T *d_dist_out, int device, void *stream) {
+                                  T *d_dist_out, int device, void *stream, bool signed_keys = false) {
     if (nq == 0 || k_out == 0) return PN_OK;
     if (!d_idx_parts || !d_dist_parts || !d_idx_out || !d_dist_out) return fail(PN_ERR_INVALID, "NULL argument");
     if (n_parts == 0 || k_part == 0) return fail(PN_ERR_INVALID, "empty parts");
@@ -2568,10 +2568,27 @@ static int merge_topk_device_impl(const uint64_t *d_idx_parts, const T *d_dist_p
     PNCHK(check_device(device));
     DeviceGuard g(device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", device);
-    HIPCHK(Ops<T>::merge(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq, (int)k_part,
-                         (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream, nullptr, nullptr, 0, nullptr));
+    if constexpr (sizeof(T) == 4)
+        HIPCHK(launch_merge_topk_f32(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq,
+                                     (int)k_part, (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream, nullptr, nullptr, 0,
+                                     nullptr, signed_keys));
+    else
+        HIPCHK(launch_merge_topk_f64(d_idx_parts, d_dist_parts, (int)n_parts, idx_part_stride, dist_part_stride, (int)nq,
+                                     (int)k_part, (int)k_out, d_idx_out, d_dist_out, (hipStream_t)stream, nullptr, nullptr, 0,
+                                     nullptr, signed_keys));
     return PN_OK;
 }
+namespace pn {
+// the shard merge with the key order named (signed_keys: a Cosine handle's distances, sharded.hip)
+int merge_topk_device_keys_f32(const uint64_t *pi, const float *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp,
+                               size_t ko, uint64_t *oi, float *od, int device, void *stream, bool signed_keys) {
+    return merge_topk_device_impl<float>(pi, pd, np, is, ds, nq, kp, ko, oi, od, device, stream, signed_keys);
+}
+int merge_topk_device_keys_f64(const uint64_t *pi, const double *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp,
+                               size_t ko, uint64_t *oi, double *od, int device, void *stream, bool signed_keys) {
+    return merge_topk_device_impl<double>(pi, pd, np, is, ds, nq, kp, ko, oi, od, device, stream, signed_keys);
+}
+}  // namespace pn
 extern "C" int pn_merge_topk_device_f32(const uint64_t *d_idx_parts, const float *d_dist_parts, size_t n_parts,
                                         size_t idx_part_stride, size_t dist_part_stride, size_t nq, size_t k_part,
                                         size_t k_out, uint64_t *d_idx_out, float *d_dist_out, int device,

@@ -157,11 +157,13 @@ hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t 
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
-                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
+                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr,
+                                 bool signed_keys = false);
 hipError_t launch_merge_topk_f64(const uint64_t *idx_parts, const double *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, double *dist_out, hipStream_t s, const uint32_t *nq_dev = nullptr,
-                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr);
+                                 const uint32_t *osel = nullptr, size_t out_stride = 0, uint32_t *host_count = nullptr,
+                                 bool signed_keys = false);
 // gather rows sel[off + i] of src into dst row i / scatter result rows i back to query sel[off + i], for
 // i < min(max_rows, *nsel - off): the count stays on the device
 template <typename T>  // T = float | double (explicitly instantiated)
@@ -326,4 +328,8 @@ int query_device_strided_f32(const pn_index *ix, const float *d_q, size_t nq, si
                              uint64_t *d_idx, float *d_dist, size_t out_stride, hipStream_t s);
 int query_device_strided_f64(const pn_index *ix, const double *d_q, size_t nq, size_t q_cols, size_t q_stride, size_t k,
                              uint64_t *d_idx, double *d_dist, size_t out_stride, hipStream_t s);
+int merge_topk_device_keys_f32(const uint64_t *pi, const float *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp,
+                               size_t ko, uint64_t *oi, float *od, int device, void *stream, bool signed_keys);
+int merge_topk_device_keys_f64(const uint64_t *pi, const double *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp,
+                               size_t ko, uint64_t *oi, double *od, int device, void *stream, bool signed_keys);
 }  // namespace pn

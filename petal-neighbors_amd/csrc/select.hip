@@ -19,6 +19,18 @@ __device__ __forceinline__ uint64_t sel_key(double d) {
 }
 __device__ __forceinline__ float key_to_dist(uint32_t k) { return __uint_as_float(k); }
 __device__ __forceinline__ double key_to_dist(uint64_t k) { return __longlong_as_double((long long)k); }
+// dist_key_signed of exact_scan.hip (the order-preserving map of ALL floats, -0 as +0, NaN above +inf): a Cosine index's
+// distances can lie a few ulp below zero, so the shard merge orders them by these keys
+__device__ __forceinline__ uint32_t sel_key_signed(float d) {
+    if (d != d) return 0xFFC00000u;
+    const uint32_t b = __float_as_uint(d == 0.0f ? 0.0f : d);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t sel_key_signed(double d) {
+    if (d != d) return 0xFFF8000000000000ull;
+    const uint64_t b = (uint64_t)__double_as_longlong(d == 0.0 ? 0.0 : d);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
 // inverse of dist_key_signed (exact_scan.hip): keys of a Cosine index
 __device__ __forceinline__ float key_to_dist_signed(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
                                                         T *__restrict__ dist_out,
                                                         const uint32_t *__restrict__ nq_dev,
                                                         const uint32_t *__restrict__ osel, size_t out_stride,
-                                                        uint32_t *__restrict__ host_count) {
+                                                        uint32_t *__restrict__ host_count, int signed_keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
@@ -1002,7 +1014,8 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
         const size_t o = q * k_part + j;
         const uint64_t ix = idx_parts[(size_t)part * idx_part_stride + o];
         sidx[e] = ix;
-        skey[e] = (ix == ~0ull) ? KeyOf<T>::kMax : sel_key(dist_parts[(size_t)part * dist_part_stride + o]);
+        const T dv = dist_parts[(size_t)part * dist_part_stride + o];
+        skey[e] = (ix == ~0ull) ? KeyOf<T>::kMax : signed_keys ? sel_key_signed(dv) : sel_key(dv);
     }
     __syncthreads();
     uint32_t n_valid = 0;
@@ -1017,7 +1030,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const uint64_t *__restri
         const uint32_t r = rank_of<KeyT, uint64_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)k_out) {
             idx_out[qo * out_stride + r] = ix;
-            dist_out[qo * out_stride + r] = key_to_dist(k);
+            dist_out[qo * out_stride + r] = signed_keys ? key_to_dist_signed(k) : key_to_dist(k);
         }
     }
     // absent tail (fewer than k_out valid entries over all parts)
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
                                                                T *__restrict__ dist_out,
                                                                const uint32_t *__restrict__ nq_dev,
                                                                const uint32_t *__restrict__ osel, size_t out_stride,
-                                                               uint32_t *__restrict__ host_count) {
+                                                               uint32_t *__restrict__ host_count, int signed_keys) {
     using KeyT = typename KeyOf<T>::type;
     const int lane = threadIdx.x;
     const size_t q = blockIdx.x;
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
         n_valid += nv;
         for (uint32_t j = (uint32_t)lane; j < (nv < lim ? nv : lim); j += 64) {
             const uint64_t ix = pi[j];
-            const KeyT key = sel_key(pd[j]);
+            const KeyT key = signed_keys ? sel_key_signed(pd[j]) : sel_key(pd[j]);
             uint32_t rank = j;
             for (int o = 0; o < n_parts && rank < ko; ++o) {
                 if (o == p) continue;
@@ -1075,7 +1088,7 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
                 while (a < b) {
                     const uint32_t mid = (a + b) >> 1;
                     const uint64_t mi = oi[mid];
-                    const KeyT mk = sel_key(od[mid]);
+                    const KeyT mk = signed_keys ? sel_key_signed(od[mid]) : sel_key(od[mid]);
                     const bool below = mi != ~0ull && (mk < key || (mk == key && mi < ix));
                     if (below) a = mid + 1; else b = mid;
                 }
@@ -1083,7 +1096,7 @@ __global__ __launch_bounds__(64) void merge_sorted_topk_kernel(const uint64_t *_
             }
             if (rank < ko) {
                 idx_out[qo * out_stride + rank] = ix;
-                dist_out[qo * out_stride + rank] = key_to_dist(key);
+                dist_out[qo * out_stride + rank] = signed_keys ? key_to_dist_signed(key) : key_to_dist(key);
             }
         }
     }
@@ -1097,33 +1110,33 @@ template <typename T>
 static hipError_t launch_merge_topk(const uint64_t *idx_parts, const T *dist_parts, int n_parts, size_t idx_part_stride,
                                     size_t dist_part_stride, int nq, int k_part, int k_out, uint64_t *idx_out,
                                     T *dist_out, hipStream_t s, const uint32_t *nq_dev, const uint32_t *osel,
-                                    size_t out_stride, uint32_t *host_count) {
+                                    size_t out_stride, uint32_t *host_count, bool signed_keys) {
     const size_t sh = (size_t)n_parts * k_part * (8 + sizeof(typename KeyOf<T>::type));
     if (out_stride == 0) out_stride = (size_t)k_out;
     if (sh > 64 * 1024) {  // beyond the LDS-resident merge: the rank-by-binary-search merge of sorted parts
         hipLaunchKernelGGL(merge_sorted_topk_kernel<T>, dim3((unsigned)nq), dim3(64), 0, s, idx_parts, dist_parts, n_parts,
                            idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel,
-                           out_stride, host_count);
+                           out_stride, host_count, signed_keys ? 1 : 0);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(merge_topk_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s, idx_parts, dist_parts, n_parts,
                        idx_part_stride, dist_part_stride, nq, k_part, k_out, idx_out, dist_out, nq_dev, osel, out_stride,
-                       host_count);
+                       host_count, signed_keys ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_merge_topk_f32(const uint64_t *idx_parts, const float *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, float *dist_out, hipStream_t s, const uint32_t *nq_dev,
-                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
+                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count, bool signed_keys) {
     return launch_merge_topk<float>(idx_parts, dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part, k_out,
-                                    idx_out, dist_out, s, nq_dev, osel, out_stride, host_count);
+                                    idx_out, dist_out, s, nq_dev, osel, out_stride, host_count, signed_keys);
 }
 hipError_t launch_merge_topk_f64(const uint64_t *idx_parts, const double *dist_parts, int n_parts,
                                  size_t idx_part_stride, size_t dist_part_stride, int nq, int k_part, int k_out,
                                  uint64_t *idx_out, double *dist_out, hipStream_t s, const uint32_t *nq_dev,
-                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count) {
+                                 const uint32_t *osel, size_t out_stride, uint32_t *host_count, bool signed_keys) {
     return launch_merge_topk<double>(idx_parts, dist_parts, n_parts, idx_part_stride, dist_part_stride, nq, k_part, k_out,
-                                     idx_out, dist_out, s, nq_dev, osel, out_stride, host_count);
+                                     idx_out, dist_out, s, nq_dev, osel, out_stride, host_count, signed_keys);
 }
 
 // ---------------------------------------------------------------------------

@@ -212,6 +212,7 @@ struct SetGuard {
 
 struct pn_sharded {
     int elem_bytes = 4;  // 4: f32 corpus and queries (the *_f32 entry points), 8: f64
+    int metric = 0;      // 0 Euclidean, 1 Cosine (every shard a pn_index_create_cosine_* index; the merge orders signed keys)
     int profile = 0;  // PN_OPT_PROFILE (also forwarded to the shards)
     uint64_t n_total = 0;
     size_t dim = 0;
@@ -237,8 +238,8 @@ static size_t packed_words(size_t nq, size_t kp) {
 // src/ball_tree.rs:26-30)
 template <typename T> struct ShT;
 template <> struct ShT<float> {
-    static int create(const float *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o) {
-        return pn_index_create_f32(p, n, c, rs, cs, dev, o);
+    static int create(const float *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o, int metric) {
+        return metric == 1 ? pn_index_create_cosine_f32(p, n, c, rs, cs, dev, o) : pn_index_create_f32(p, n, c, rs, cs, dev, o);
     }
     static int create_device(const float *p, size_t n, size_t c, size_t rs, int dev, void *st, pn_index **o) {
         return pn_index_create_device_f32(p, n, c, rs, dev, st, o);
@@ -248,8 +249,8 @@ template <> struct ShT<float> {
         return query_device_strided_f32(ix, q, nq, qc, qs, k, oi, od, os, s);
     }
     static int merge(const uint64_t *pi, const float *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp, size_t ko,
-                     uint64_t *oi, float *od, int dev, void *s) {
-        return pn_merge_topk_device_f32(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s);
+                     uint64_t *oi, float *od, int dev, void *s, bool signed_keys) {
+        return merge_topk_device_keys_f32(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s, signed_keys);
     }
     static int radius(const pn_index *ix, const float *q, size_t nq, size_t qc, ptrdiff_t qs, float r, uint64_t *off,
                       uint64_t **out) {
@@ -257,8 +258,8 @@ template <> struct ShT<float> {
     }
 };
 template <> struct ShT<double> {
-    static int create(const double *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o) {
-        return pn_index_create_f64(p, n, c, rs, cs, dev, o);
+    static int create(const double *p, size_t n, size_t c, ptrdiff_t rs, ptrdiff_t cs, int dev, pn_index **o, int metric) {
+        return metric == 1 ? pn_index_create_cosine_f64(p, n, c, rs, cs, dev, o) : pn_index_create_f64(p, n, c, rs, cs, dev, o);
     }
     static int create_device(const double *p, size_t n, size_t c, size_t rs, int dev, void *st, pn_index **o) {
         return pn_index_create_device_f64(p, n, c, rs, dev, st, o);
@@ -268,8 +269,8 @@ template <> struct ShT<double> {
         return query_device_strided_f64(ix, q, nq, qc, qs, k, oi, od, os, s);
     }
     static int merge(const uint64_t *pi, const double *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp, size_t ko,
-                     uint64_t *oi, double *od, int dev, void *s) {
-        return pn_merge_topk_device_f64(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s);
+                     uint64_t *oi, double *od, int dev, void *s, bool signed_keys) {
+        return merge_topk_device_keys_f64(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s, signed_keys);
     }
     static int radius(const pn_index *ix, const double *q, size_t nq, size_t qc, ptrdiff_t qs, double r, uint64_t *off,
                       uint64_t **out) {
@@ -334,7 +335,7 @@ static int init_dev_resources(Dev &d) {
 // (src/ball_tree.rs:44-49), done on the whole array before anything is split.
 template <typename T>
 static int sharded_create(const T *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride, ptrdiff_t col_stride,
-                          const int *devices, int n_devices, pn_sharded **out) {
+                          const int *devices, int n_devices, pn_sharded **out, int metric = 0) {
     if (!out) return set_error(PN_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n_rows == 0) return set_error(PN_ERR_EMPTY, "array is empty");
@@ -353,6 +354,7 @@ static int sharded_create(const T *points, size_t n_rows, size_t n_cols, ptrdiff
     pn_sharded *sh = new (std::nothrow) pn_sharded();
     if (!sh) return set_error(PN_ERR_NOMEM, "host allocation failed");
     sh->elem_bytes = (int)sizeof(T);
+    sh->metric = metric;
     sh->n_total = n_rows;
     sh->dim = n_cols;
     sh->n_shards = n_devices;
@@ -377,7 +379,7 @@ static int sharded_create(const T *points, size_t n_rows, size_t n_cols, ptrdiff
         p.dev_slot = (int)(std::find(distinct.begin(), distinct.end(), devices[g]) - distinct.begin());
         if (p.hi > p.lo) {
             rc = ShT<T>::create(points + (size_t)p.lo * (size_t)row_stride, (size_t)(p.hi - p.lo), n_cols, row_stride,
-                                col_stride, devices[g], &p.ix);
+                                col_stride, devices[g], &p.ix, metric);
             if (rc == PN_OK) rc = pn_index_set_option(p.ix, PN_OPT_INDEX_BASE, (int64_t)p.lo);
         }
         sh->parts.push_back(p);
@@ -469,6 +471,17 @@ extern "C" int pn_sharded_create_f32(const float *points, size_t n_rows, size_t 
 extern "C" int pn_sharded_create_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
                                      ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
     return sharded_create<double>(points, n_rows, n_cols, row_stride, col_stride, devices, n_devices, out);
+}
+// BallTree::new(points, Cosine) over row shards driven by this process (one process per GPU: not offered -- there is no
+// Cosine index from rows in HBM).  Every shard is a pn_index_create_cosine_* index (exact scan under Cosine::distance); the
+// part merge orders the order-preserving keys of ALL floats, as the single index does (distances a few ulp below zero).
+extern "C" int pn_sharded_create_cosine_f32(const float *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                            ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+    return sharded_create<float>(points, n_rows, n_cols, row_stride, col_stride, devices, n_devices, out, 1);
+}
+extern "C" int pn_sharded_create_cosine_f64(const double *points, size_t n_rows, size_t n_cols, ptrdiff_t row_stride,
+                                            ptrdiff_t col_stride, const int *devices, int n_devices, pn_sharded **out) {
+    return sharded_create<double>(points, n_rows, n_cols, row_stride, col_stride, devices, n_devices, out, 1);
 }
 extern "C" int pn_sharded_create_rank_device_f32(const float *d_rows, size_t n_local, size_t n_cols, size_t row_stride,
                                                  uint64_t n_total, int rank, int world, const void *comm_id, int device,
@@ -594,7 +607,7 @@ static int enqueue_local(const pn_sharded *sh, Dev &d, const T *d_q, size_t nq, 
         if (p.ix) SPN(ShT<T>::query_strided(p.ix, d_q, nq, q_cols, q_stride, k < kp ? k : kp, pi, pd, kp, s));
     }
     return ShT<T>::merge(stage, reinterpret_cast<const T *>(stage + nq * kp), np, pwords, kDW * pwords, nq, kp, kd, oi, od,
-                         d.device, s);
+                         d.device, s, sh->metric == 1);
 }
 
 // exchange + final merge of one chunk on one GPU, enqueued on `s`: one all-gather of the packed buffer, then the
@@ -605,7 +618,7 @@ static int enqueue_merge(const pn_sharded *sh, Dev &d, size_t nq, size_t kd, siz
     const size_t words = packed_words<T>(nq, kd);
     const uint64_t *g = (const uint64_t *)d.gathered[set].p;
     return ShT<T>::merge(g, reinterpret_cast<const T *>(g + nq * kd), (size_t)sh->world, words, (8 / sizeof(T)) * words, nq,
-                         kd, k_out, d_idx, d_dist, d.device, s);
+                         kd, k_out, d_idx, d_dist, d.device, s, sh->metric == 1);
 }
 
 static size_t k_part_of(const pn_sharded *sh, size_t k) {  // slots per query a SHARD fills

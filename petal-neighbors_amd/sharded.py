@@ -51,9 +51,9 @@ class ShardedIndex:
         self.mfma_eligible, self.bf16_eligible = bool(info.mfma_eligible), bool(info.bf16_eligible)
 
     @classmethod
-    def from_host(cls, points, devices):
+    def from_host(cls, points, devices, metric=None):
         """``BallTree::new`` over ``len(devices)`` row shards driven by this process; shard g lives on
-        ``devices[g]`` (a device may be named several times)."""
+        ``devices[g]`` (a device may be named several times).  ``metric``: None / ``Euclidean()`` or ``Cosine()``."""
         from . import _lib
         from .errors import check
         a = np.asarray(points)
@@ -66,7 +66,9 @@ class ShardedIndex:
         rs, cs = (a.strides[0] // item, a.strides[1] // item) if n and d else (max(d, 1), 1)
         devs = (C.c_int * len(devices))(*[int(x) for x in devices])
         h = C.c_void_p(0)
-        create = _lib.lib().pn_sharded_create_f64 if a.dtype == np.float64 else _lib.lib().pn_sharded_create_f32
+        from .distance import Cosine
+        sfx = "f64" if a.dtype == np.float64 else "f32"
+        create = getattr(_lib.lib(), ("pn_sharded_create_cosine_" if isinstance(metric, Cosine) else "pn_sharded_create_") + sfx)
         check(create(a.ctypes.data if a.size else None, n, d, rs, cs if d > 1 else 1, devs, len(devices), C.byref(h)))
         return cls(h.value, keep=a, dtype=a.dtype)
 

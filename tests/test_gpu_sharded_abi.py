@@ -334,3 +334,31 @@ def test_f64_rank_entry_at_world_size_one(pn, oracle_mod):
     torch.cuda.synchronize()
     assert _same(gi.cpu().numpy(), gd.cpu().numpy(), *oracle_mod.brute_knn(pts, qs, k))
     sh.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shards", [2, 5])
+def test_cosine_shards_equal_the_single_cosine_index(pn, dtype, shards):
+    """BallTree::new(points, Cosine) over row shards: every shard a Cosine index, the part merge on the order-preserving
+    keys of ALL floats (rows parallel to a query have distances a few ulp around zero, some below it).  Answers equal the
+    single Cosine index's bit for bit, k-NN and radius."""
+    from petal_neighbors_amd import _lib
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 6000, 24, 60, 9
+    pts = (rng.random((n, dim)) - 0.3).astype(dtype)
+    pts[100:140] = pts[7] * np.linspace(0.5, 3.0, 40, dtype=dtype)[:, None]   # parallel to row 7: cosine distance ~ 0
+    pts[5000:5020] = pts[7] * dtype(1.7)
+    qs = np.concatenate([pts[7:8], pts[3:4] * dtype(2.5), (rng.random((nq - 2, dim)) - 0.3).astype(dtype)])
+    from petal_neighbors_amd.distance import Cosine
+    one = pn.BallTree.new(pts, Cosine())
+    sh = pn.ShardedIndex.from_host(pts, [0] * shards, metric=Cosine())
+    sh.set_option(_lib.PN_OPT_EXCHANGE_ALWAYS, 1)
+    wi, wd = one.query_batch(qs, k)
+    gi, gd = sh.query_batch(qs, k)
+    assert gd.dtype == np.dtype(dtype) and _same(gi, gd, wi, wd)
+    assert (wd[0] <= 0).any() or (wd[:2] < 1e-6).all()     # the near-zero group is really in play
+    r = float(np.median(wd[:, 4]))
+    o1, i1 = one.query_radius_batch(qs, r)
+    o2, i2 = sh.query_radius_batch(qs, r)
+    assert np.array_equal(o1, o2) and np.array_equal(i1, i2)
+    sh.close()
