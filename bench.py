@@ -321,7 +321,7 @@ def bench_f64(args):
         "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
         "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),
     }
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def plumbing(args):
@@ -384,10 +384,35 @@ def plumbing(args):
                                    "radius 64x10 r=0.2) + BASELINE.json configs[0] (1000x3 k=2) + nq=1 at the headline shape"},
             "results": res, "cpu_baseline": {"kind": "port", "cores": 1,
                                              "sample": "C restatement of petal-neighbors' BallTree (oracle/), same arrays, one thread"}}
-    print(json.dumps(line), flush=True)
+    emit(line)
+
+
+# The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner to fd 1 when
+# the first communicator is created), so for the life of the process fd 1 is pointed at stderr and the line goes to the
+# saved descriptor of the real stdout.
+_REAL_STDOUT = None
+
+
+def _keep_stdout_for_the_line():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, data)
 
 
 def main():
+    _keep_stdout_for_the_line()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -423,7 +448,7 @@ def main():
             port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.run(cmd).returncode)
+        sys.exit(subprocess.run(cmd, stdout=_REAL_STDOUT).returncode)  # (the ranks' line goes to the real stdout)
 
     if args.config == "c1":
         return plumbing(args)
@@ -629,7 +654,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, dim, k)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
