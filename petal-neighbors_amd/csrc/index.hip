@@ -1341,8 +1341,10 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         // (a refresher holds up to 512 keys of a query's union in registers -- and at k = 100 (r = 330, 128-slot buffers)
         // sharing measured 6 % SLOWER, 3.44 -> 3.65 ms: there a buffer's own compactions already keep its threshold near
         // the k'-th bound; a refresher pass over the queries takes
-        // ~0.25 ms, so short runs end before it pays: a 125 k-row shard of C2, 163 tiles per run, measured 2 % slower)
-        if (slots >= 4 && rank <= 256 && rank < p.nseg * p.cap && r_tiles / per_tile >= 512) {
+        // ~0.25 ms, so short runs end before it pays: a 125 k-row shard of C2, 163 tiles per run, measured 2-4 % slower)
+        size_t sh_min_run = 320;  // (same-device A/B: 326-tile runs, a 250 k-row shard of C2, 0.88-0.91 -> 0.875-0.885 ms; 163-tile runs +4 %)
+        if (const char *e = getenv("PN_EXP_SH_MIN_RUN")) sh_min_run = (size_t)atol(e);  // experiments only
+        if (slots >= 4 && rank <= 256 && rank < p.nseg * p.cap && r_tiles / per_tile >= sh_min_run) {
             p.n_refresh = slots > 64 ? 64 : slots;
             p.sh_rank = rank;
         }
