@@ -16,3 +16,12 @@ def test_random_shapes_match_the_oracle(pn, oracle_mod, seed):
     rng = np.random.default_rng(seed)
     for c in range(6):
         assert fuzz_knn.run_case(100 * seed + c, rng)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_sharded_handles_match_the_oracle(pn, oracle_mod, seed):
+    """tests/fuzz_sharded.py: virtual shards on one GPU, f32 / f64, Euclidean / Cosine, k-NN and radius."""
+    import fuzz_sharded
+    rng = np.random.default_rng(seed)
+    for c in range(6):
+        assert fuzz_sharded.run_case(100 * seed + c, rng)
