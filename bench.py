@@ -94,8 +94,16 @@ def usable_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(n, dim, k, budget_queries=None):
-    """Faithful ball tree (oracle/oracle_impl.h) on this host: all-core QPS, single-thread QPS, build s."""
+def cpu_baseline(n, dim, k, gpu_out=None, budget_queries=None):
+    """Faithful ball tree (oracle/oracle_impl.h) on this host: single-thread QPS over >= 64 queries (what
+    benches/ball_tree.rs:43-62 times: the reference is single-threaded), all-core QPS with one query per thread over
+    >= 8 queries per thread (what `Euclidean: Sync`, src/distance.rs:19, lets a caller do), build s -- SURVEY.md 8(d).
+
+    The tree's queries are the FIRST rows of the GPU batch (same seed, same counters), and its answers are kept: with
+    gpu_out = (idx, dist) of the GPU step they are compared entry by entry (oracle.compare_knn: distances bit for bit,
+    indices outside groups of exactly equal distances) -- the reference's pruned walk (src/ball_tree.rs:203-243, pruning
+    on fl(|q - c| - R), :473-481) against the GPU pipeline on the same f32 data at the headline scale, not only each of
+    them against the brute force."""
     import oracle
     oracle.build()
     cores = usable_cores()
@@ -105,22 +113,32 @@ def cpu_baseline(n, dim, k, budget_queries=None):
     t0 = time.perf_counter()
     tree = oracle.Tree(pts, build_threads_log2=par)
     t_build = time.perf_counter() - t0
-    nq1 = 4
-    nqa = budget_queries or max(2 * cores, 16)
+    nq1 = 64
+    nqa = budget_queries or max(8 * cores, 64)
     qs = oracle.fill_uniform((nq1 + nqa) * dim, SEED_Q).reshape(nq1 + nqa, dim)
     t0 = time.perf_counter()
-    tree.query_batch(qs[:nq1], k, nthreads=1)
+    i1, d1 = tree.query_batch(qs[:nq1], k, nthreads=1)
     t1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    tree.query_batch(qs[nq1:], k, nthreads=cores)
+    ia, da = tree.query_batch(qs[nq1:], k, nthreads=cores)
     ta = time.perf_counter() - t0
-    return {
+    res = {
         "value": round(nqa / ta, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-        "single_thread_qps": round(nq1 / t1, 3), "build_s": round(t_build, 2),
+        "single_thread_qps": round(nq1 / t1, 3), "single_thread_queries": nq1, "build_s": round(t_build, 2),
         "sample": (f"C restatement of petal-neighbors' BallTree (oracle/), {n_cpu}x{dim} f32 corpus"
                    f"{'' if n_cpu == n else ' (sub-sampled from %d rows)' % n}, k={k}: {nqa} queries on {cores} threads "
-                   f"(one query per thread), {nq1} queries on 1 thread; tree build ({2**par} threads) {t_build:.1f} s excluded"),
+                   f"(one query per thread, {nqa // cores} per thread), {nq1} queries on 1 thread; tree build "
+                   f"({2**par} threads) {t_build:.1f} s excluded"),
     }
+    if gpu_out is not None and n_cpu == n and gpu_out[0].shape[0] >= nq1 + nqa:
+        m = nq1 + nqa
+        gi = gpu_out[0][:m].cpu().numpy().astype(np.uint64)
+        gd = gpu_out[1][:m].cpu().numpy()
+        cmp = oracle.compare_knn(np.concatenate([i1, ia]), np.concatenate([d1, da]), gi, gd)
+        res["agrees_with_gpu"] = bool(cmp["agree"])
+        res["agreement"] = {**cmp, "what": (f"faithful ball-tree walk vs the GPU step's answers on the first {m} queries of "
+                                            f"the batch: distances bit for bit, indices outside exact-tie groups")}
+    return res
 
 
 def verify(out, queries, n, dim, nq, k, rank, world, index, gen):
@@ -653,7 +671,10 @@ def main():
             "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, dim, k)
+            cb = cpu_baseline(n, dim, k, gpu_out=out if args.mode == "knn" else None)
+            line["cpu_baseline"] = cb
+            if cb.get("agrees_with_gpu") is False:  # the tree walk and the GPU disagree outside exact ties: not verified
+                line["verified"] = False
         emit(line)
     if dist:
         dist.barrier()

@@ -356,3 +356,54 @@ def fill_uniform(count, seed, first_ctr=0, dtype=np.float32):
     out = np.empty(count, dtype=dtype)
     getattr(lib(), f"oracle_fill_uniform_{s}")(_ptr(out, ct), count, seed, first_ctr)
     return out
+
+
+# -------------------------------------------------------------- answer comparison
+def compare_knn(idx_a, dist_a, idx_b, dist_b):
+    """Two k-NN answers for the same queries (rows ascending by distance): the result contract of SURVEY.md App. A.2/A.3.
+
+    Distances must be bit-identical.  Indices must be identical except INSIDE groups of exactly equal distances, where
+    the reference's order is unspecified (tree shape + BinaryHeap internals): there the two index SETS must agree -- and
+    in the group that reaches the k-th position even the sets may differ (either member of a tie at the cut is a valid
+    k-th neighbour).  Returns a dict of counts (queries): ``dist_mismatch``, ``idx_mismatch`` (outside tie groups or a
+    set difference inside a closed one), ``tie_reordered`` (same sets, different order), ``tie_at_cut`` (sets differ only
+    in the group cut by k), and ``first_bad`` = the first offending query or -1."""
+    ia, ib = np.asarray(idx_a).astype(np.uint64), np.asarray(idx_b).astype(np.uint64)
+    da, db = np.ascontiguousarray(dist_a), np.ascontiguousarray(dist_b)
+    assert ia.shape == ib.shape == da.shape == db.shape and da.dtype == db.dtype, "answers of different shape or type"
+    nq, k = ia.shape
+    ut = np.uint32 if da.dtype == np.float32 else np.uint64
+    ba, bb = da.view(ut), db.view(ut)
+    out = dict(queries=int(nq), dist_mismatch=0, idx_mismatch=0, tie_reordered=0, tie_at_cut=0, first_bad=-1)
+    drow = (ba != bb).any(axis=1) if k else np.zeros(nq, bool)
+    irow = (ia != ib).any(axis=1) if k else np.zeros(nq, bool)
+    for q in np.nonzero(drow | irow)[0]:
+        if drow[q]:
+            out["dist_mismatch"] += 1
+            out["first_bad"] = int(q) if out["first_bad"] < 0 else out["first_bad"]
+            continue
+        bad = reordered = cut = False
+        j = 0
+        while j < k:
+            e = j + 1
+            while e < k and ba[q, e] == ba[q, j]:
+                e += 1
+            if not np.array_equal(ia[q, j:e], ib[q, j:e]):
+                if np.array_equal(np.sort(ia[q, j:e]), np.sort(ib[q, j:e])):
+                    reordered = True
+                elif e == k:
+                    # the group that the cut at k goes through: members beyond k exist only if more rows tie at this
+                    # distance, which the caller cannot see from k entries -- reported separately, not as a mismatch
+                    cut = True
+                else:
+                    bad = True
+            j = e
+        if bad:
+            out["idx_mismatch"] += 1
+            out["first_bad"] = int(q) if out["first_bad"] < 0 else out["first_bad"]
+        elif cut:
+            out["tie_at_cut"] += 1
+        elif reordered:
+            out["tie_reordered"] += 1
+    out["agree"] = out["dist_mismatch"] == 0 and out["idx_mismatch"] == 0
+    return out

@@ -77,6 +77,7 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
     if flags_then != flags_now:
         force = True
     objs = []
+    jobs = []  # compile commands, run side by side below (the units are independent; bf16_filter.hip alone takes minutes)
     me = os.path.abspath(__file__)
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
@@ -91,14 +92,21 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
         if force or _stale(obj, [sp, me] + HEADERS):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
             cmd = [cc] + COMMON + extra + DIAG + lang + ["-c", sp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            jobs.append(cmd)
         asm = os.path.join(BUILD, os.path.splitext(src)[0] + ".s")
         want_asm = keep_asm is True or (keep_asm and os.path.splitext(src)[0] in keep_asm)  # True: every unit
         if want_asm and src.endswith(".hip") and (force or _stale(asm, [sp, me] + HEADERS)):
             cmd = [cc] + COMMON + extra + DIAG + ["-x", "hip", "--cuda-device-only", "-S", sp, "-o", asm]
+            jobs.append(cmd)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("PN_BUILD_JOBS", "6")))) as ex:
+            list(ex.map(run, jobs))  # (re-raises the first failure)
     if force or _stale(LIB, objs):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         if verbose:

@@ -1406,7 +1406,8 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
             BF_COUNT(2, 1);
             bf_compact<M, SH>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
             if (jq == j) {
-                tau = s2f(T);
+                tau = fminf(tau, s2f(T));  // never RAISED (a shared word may have lowered tau below entries stored earlier): what is
+                                           // reported must be <= every value rows were dropped against
                 cnt = nn;
             }
         } while (need);
@@ -1468,7 +1469,8 @@ __device__ __forceinline__ void bf_flush(BfPend &pd, float &tau, uint32_t &cnt, 
             BF_COUNT(2, 1);
             bf_compact<M>(ce_blk + (size_t)j * CAP, cj, kp, lane, T, nn);
             if (jq == j) {
-                tau = s2f(T);
+                tau = fminf(tau, s2f(T));  // never RAISED (a shared word may have lowered tau below entries stored earlier): what is
+                                           // reported must be <= every value rows were dropped against
                 cnt = nn;
             }
         } while (need);
@@ -2195,7 +2197,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(const char *__restr
                         if (jj[b] >= 0) {
                             uint32_t T, nn;
                             bf_compact_finish<M>(ce_blk + (size_t)jj[b] * CAP, key[b], ixs[b], cj[b], kp, lane, T, nn);
-                            if (jq == jj[b]) { tau = s2f(T); cnt = nn; }
+                            if (jq == jj[b]) { tau = fminf(tau, s2f(T)); cnt = nn; }
                         }
                     }
                 }
@@ -2559,7 +2561,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt0, j);
         uint32_t T, nn;
         bf_compact<M>(ce_blk0 + (size_t)j * CAP, cj, kp, lane, T, nn);
-        if (jq == j) { tau0 = s2f(T); cnt0 = nn; }
+        if (jq == j) { tau0 = fminf(tau0, s2f(T)); cnt0 = nn; }
     }
     need = RAD ? 0ull : __ballot(h == 0 && cnt1 > kp);
     while (need) {
@@ -2568,7 +2570,7 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cnt1, j);
         uint32_t T, nn;
         bf_compact<M>(ce_blk1 + (size_t)j * CAP, cj, kp, lane, T, nn);
-        if (jq == j) { tau1 = s2f(T); cnt1 = nn; }
+        if (jq == j) { tau1 = fminf(tau1, s2f(T)); cnt1 = nn; }
     }
 #if defined(PN_DIAG_BF_NOSTORE) || defined(PN_DIAG_BF_NOSLOW)
     cnt0 = 0;

@@ -1082,6 +1082,32 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 //   level 1: all R rows may sit in one segment (corpus sorted by cluster): k' = R + 6 sqrt(R);
 //   level 2: tier off.
 // A call that had to hand more than 1/16 of its queries to the next tier raises the index's level (sticky).
+// Experiment knobs of the planner (tools/ sweeps): read from the environment ONCE per process and validated -- the
+// planner runs for every query chunk, incl. the one-point-per-call path, and a stray or malformed variable must not
+// feed NaN or negative numbers into plan geometry.  0 = not set.
+struct PlanKnobs {
+    double scout_lambda = 0.0, scout_cap = 0.0;
+    size_t sh_min_run = 0;
+    bool debug = false;
+};
+static const PlanKnobs &plan_knobs() {
+    static const PlanKnobs k = [] {
+        PlanKnobs v;
+        auto num = [](const char *name, double lo, double hi) -> double {
+            const char *e = getenv(name);
+            if (!e) return 0.0;
+            char *end = nullptr;
+            const double x = strtod(e, &end);
+            return (end != e && x >= lo && x <= hi) ? x : 0.0;  // (NaN fails both comparisons)
+        };
+        v.scout_lambda = num("PN_EXP_SCOUT_LAMBDA", 0.01, 64.0);
+        v.scout_cap = num("PN_EXP_SCOUT_CAP", 1.0, 64.0);
+        v.sh_min_run = (size_t)num("PN_EXP_SH_MIN_RUN", 1.0, 1.0e6);
+        v.debug = getenv("PN_DEBUG_PLAN") != nullptr;
+        return v;
+    }();
+    return k;
+}
 struct Bf16Plan {
     int n_wg, split, nseg, kp, cap, scout_max;
     bool ok, aligned;
@@ -1160,8 +1186,8 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
     if (p.ok && level == 0 && ix->filter_slots == 0 && segs >= 4.0) {
         const size_t run_len = q_tiles * r_tiles / (size_t)p.n_wg;
         double lam_w = 1.2, t_cap_w = 16.0;
-        if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_w = atof(e);  // experiments only
-        if (const char *e = getenv("PN_EXP_SCOUT_CAP")) t_cap_w = atof(e);   // experiments only
+        if (plan_knobs().scout_lambda > 0.0) lam_w = plan_knobs().scout_lambda;  // experiments only
+        if (plan_knobs().scout_cap > 0.0) t_cap_w = plan_knobs().scout_cap;      // experiments only
         double t = lam_w * (double)ix->n / (R * segs * 128.0);  // tiles per run for lambda = 1.2
         if (t > t_cap_w) t = t_cap_w;
         if (t > (double)run_len / 8.0) t = (double)run_len / 8.0;
@@ -1300,7 +1326,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         // 10M x 128, 10^5 queries, k = 100 (same device): 223 (64-tile cap) / 218 / 213 / 209 ms at 1.2 / 1.2 / 4 / 9.
         // The cap of 64 tiles per workgroup (from the in-run scout of round 1) is gone: a nineteenth of the run bounds it.
         double lam_target = R / 27.0 > 1.2 ? R / 27.0 : 1.2;
-        if (const char *e = getenv("PN_EXP_SCOUT_LAMBDA")) lam_target = atof(e);  // experiments only
+        if (plan_knobs().scout_lambda > 0.0) lam_target = plan_knobs().scout_lambda;  // experiments only
         double t = lam_target * (double)r_tiles / (R * (double)per_tile);  // tiles per workgroup
         // (never more than a nineteenth of the run -- what lambda = 1.2 asks for at k = 10; k = 1 would ask for a fifth)
         if (t > (double)run_len / 19.0) t = (double)run_len / 19.0;
@@ -1343,13 +1369,13 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
         // the k'-th bound; a refresher pass over the queries takes
         // ~0.25 ms, so short runs end before it pays: a 125 k-row shard of C2, 163 tiles per run, measured 2-4 % slower)
         size_t sh_min_run = 320;  // (same-device A/B: 326-tile runs, a 250 k-row shard of C2, 0.88-0.91 -> 0.875-0.885 ms; 163-tile runs +4 %)
-        if (const char *e = getenv("PN_EXP_SH_MIN_RUN")) sh_min_run = (size_t)atol(e);  // experiments only
+        if (plan_knobs().sh_min_run) sh_min_run = plan_knobs().sh_min_run;  // experiments only
         if (slots >= 4 && rank <= 256 && rank < p.nseg * p.cap && r_tiles / per_tile >= sh_min_run) {
             p.n_refresh = slots > 64 ? 64 : slots;
             p.sh_rank = rank;
         }
     }
-    if (getenv("PN_DEBUG_PLAN"))  // development aid: what a call was planned as
+    if (plan_knobs().debug)  // development aid: what a call was planned as
         fprintf(stderr, "bf16_plan: n %zu q_tiles %zu k %zu R %.0f: n_wg %d per_tile %zu split %d nseg %d kp %d cap %d aligned %d "
                         "shared_scout %d scout_tiles %d seed_rank %d scout_max %d n_refresh %d sh_rank %d\n",
                 ix->n, q_tiles, kout, R, p.n_wg, per_tile, p.split, p.nseg, p.kp, p.cap, (int)p.aligned, (int)p.shared_scout,

@@ -747,6 +747,10 @@ static int sharded_query_host(const pn_sharded *sh, const T *queries, size_t nq,
     for (Dev &d : devs) {
         SetGuard g(d.device);
         if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+        // behind whatever a device call on another stream still runs on these buffers; allocations outgrown by earlier
+        // calls go back now (the previous host call ended with a stream sync: without this the multi-GPU path and the
+        // one-shard early return, which never reach acquire_dev, kept every outgrown buffer until destroy -- ADVICE r3)
+        SPN(acquire_dev(d, d.stream));
         SPN(d.q.ensure(nq * qc * sizeof(T)));
         if (q_cols) {
             if (nq == 1 || (size_t)q_row_stride == q_cols)

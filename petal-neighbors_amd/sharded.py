@@ -81,12 +81,23 @@ class ShardedIndex:
         return buf.raw
 
     @classmethod
-    def from_rank_device(cls, rows, n_total: int, rank: int, world: int, comm_id: bytes, device: int, stream=None):
-        """One process per GPU: ``rows`` = this rank's shard (float32 CUDA tensor, or None for an empty shard)."""
+    def from_rank_device(cls, rows, n_total: int, rank: int, world: int, comm_id: bytes, device: int, stream=None,
+                         dtype=None):
+        """One process per GPU: ``rows`` = this rank's shard (float32 or float64 CUDA tensor, or None for an empty
+        shard).  ``dtype`` is the element type of the WHOLE job (every rank must pass the same one: the packed parts of
+        the all-gather are sized by it); it defaults to the rows' type and must be given where a rank may hold no rows."""
         import torch
         from . import _lib
         from .errors import check
         h = C.c_void_p(0)
+        if dtype is None:
+            dtype = np.float64 if (rows is not None and rows.dtype == torch.float64) else np.float32
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        f64 = dtype == np.float64
+        if rows is not None and rows.dtype != (torch.float64 if f64 else torch.float32):
+            raise ValueError("rows are %s but the job's element type is %s" % (rows.dtype, dtype))
         if rows is not None and rows.numel():
             if rows.dtype not in (torch.float32, torch.float64) or rows.dim() != 2 or not rows.is_cuda or (rows.shape[1] > 1 and rows.stride(1) != 1):
                 raise ValueError("rows must be a row-major 2-D float32 or float64 CUDA tensor")
@@ -95,7 +106,6 @@ class ShardedIndex:
         else:
             ptr, nl, d, ld, st = None, 0, (rows.shape[1] if rows is not None else 0), 1, 0
         idb = C.create_string_buffer(bytes(comm_id), _lib.PN_COMM_ID_BYTES)
-        f64 = rows is not None and rows.dtype == torch.float64
         create = _lib.lib().pn_sharded_create_rank_device_f64 if f64 else _lib.lib().pn_sharded_create_rank_device_f32
         check(create(ptr, nl, d, ld, int(n_total), int(rank), int(world), idb, int(device), C.c_void_p(st), C.byref(h)))
         return cls(h.value, dtype=np.float64 if f64 else np.float32)
@@ -206,8 +216,8 @@ class AbiShardEngine:
         self.device = device
         self.index = None
 
-    def build_rank(self, rows, n_total, rank, world, comm_id):
-        self.index = ShardedIndex.from_rank_device(rows, n_total, rank, world, comm_id, self.device)
+    def build_rank(self, rows, n_total, rank, world, comm_id, dtype=None):
+        self.index = ShardedIndex.from_rank_device(rows, n_total, rank, world, comm_id, self.device, dtype=dtype)
 
     @property
     def tree(self):  # option / statistics target (bench.py)
@@ -314,8 +324,12 @@ class ShardedBallTree:
     full corpus never has to exist in one place.
     """
 
-    def __init__(self, n_points: int, points_fn, engine=None, group=None):
+    def __init__(self, n_points: int, points_fn, engine=None, group=None, dtype=np.float32):
+        """``dtype``: element type of the whole job (float32 or float64), the same on every rank -- a rank without rows
+        has nothing else to learn it from, and the exchange is sized by it; the ranks compare theirs before any
+        communicator exists and all raise together on a mismatch."""
         import torch.distributed as dist
+        self.dtype = np.dtype(dtype)
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -331,8 +345,10 @@ class ShardedBallTree:
             # the ABI owns the exchange: all it needs from this program is the communicator id on every rank
             import torch
             rows = points_fn(self.lo, self.hi) if self.n_local > 0 else None
+            tdt = torch.float64 if self.dtype == np.float64 else torch.float32
             if rows is not None and not isinstance(rows, torch.Tensor):
-                rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(f"cuda:{engine.device}")
+                rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=self.dtype)).to(f"cuda:{engine.device}")
+            mine = self.dtype.itemsize if rows is None or rows.dtype == tdt else -int(rows.element_size())
             # Failure-symmetric: rank 0 may fail to make the id (RCCL not loadable: PN_ERR_COMM) -- it then still takes
             # part in the broadcast, with a status byte in front of an all-zero id, and EVERY rank raises after it.  (A
             # rank 0 that raised before the broadcast left the others blocked in it.)
@@ -351,7 +367,20 @@ class ShardedBallTree:
                 cid = t.cpu()
             if int(cid[0]) != 1:
                 raise err if err is not None else RuntimeError("rank 0 could not create the RCCL communicator id")
-            engine.build_rank(rows, self.n, self.rank, self.world, bytes(cid[1:].numpy().tobytes()))
+            # element sizes agreed BEFORE the communicator is made: ranks that disagree would size the all-gather
+            # differently (1.5 vs 2 words per entry) and hang or corrupt it.  Every rank sees every size and raises.
+            sizes = [mine]
+            if self.world > 1:
+                on_gpu = dist.get_backend(group) == "nccl"
+                t = torch.tensor([mine], dtype=torch.int64)
+                t = t.to(f"cuda:{engine.device}") if on_gpu else t
+                parts = [torch.empty_like(t) for _ in range(self.world)]
+                dist.all_gather(parts, t, group=group)
+                sizes = [int(x.cpu()[0]) for x in parts]
+            if any(sz != self.dtype.itemsize for sz in sizes):
+                raise ValueError("ShardedBallTree: the ranks do not agree on the element type (bytes per element by rank: "
+                                 "%s, negative = rows of another type than dtype=%s)" % (sizes, self.dtype))
+            engine.build_rank(rows, self.n, self.rank, self.world, bytes(cid[1:].numpy().tobytes()), dtype=self.dtype)
         elif self.n_local > 0:
             self.engine.build(points_fn(self.lo, self.hi), self.lo)
 

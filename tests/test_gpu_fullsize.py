@@ -218,6 +218,17 @@ def test_c5_shard_query_chunk_loop(pn, oracle_mod):
     _cleanup(tree)
 
 
+def test_c5_whole_on_one_gpu(pn, oracle_mod):
+    """configs[4] WHOLE on one GPU (the one config that had only been run as a shard under the test run):
+    10^8 x 96 f32 (38.4 GB of rows + 20.8 GB of tile images) and 10^6 queries, k = 10 -- four 262 144-query chunks over
+    1.56 M row tiles.  Properties on all 10^6 answers, the exact engine on 1 024 of them, the oracle's brute force over
+    the whole corpus (streamed to the host in chunks) on 8."""
+    n, dim, nq, k = 100_000_000, 96, 1_000_000, 10
+    tree, *_ = _run(pn, oracle_mod, n, dim, nq, k, n_exact=1024, n_oracle=8, max_fallback=nq // 2000,
+                    chunk_rows=2_500_000)
+    _cleanup(tree)
+
+
 @pytest.mark.parametrize("dtype,n,dim", [(np.float32, 16384, 128), (np.float64, 16384, 16), (np.float32, 8192, 768)])
 def test_pairwise_at_the_benched_sizes(pn, oracle_mod, dtype, n, dim):
     """distance::pairwise at the sizes of the roofline table (DESIGN.md 4.3; tools/bench_pairwise.py): the HBM-resident

@@ -1,0 +1,86 @@
+"""The parity chain closed at the headline scale ("report, not hide, any
+faithful-tree-vs-brute-force mismatch found at scale").
+
+Everywhere else the GPU is compared with the oracle's BRUTE FORCE and the faithful ball tree with the brute force on
+small corpora.  Here the two ends meet directly: the reference's pruned walk (oracle.Tree: src/ball_tree.rs:203-243 for
+k-NN, :250-294 for radius, pruning on fl(|q - c| - R), :473-481) against the GPU pipeline on the SAME f32 corpus of a
+million rows -- the first time the walk's pruning arithmetic meets f32 data at the benched scale.  Any disagreement
+outside groups of exactly equal distances fails the test and is printed query by query.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED_P, SEED_Q = 0x5EED0001, 0x5EED0002  # bench.py's corpus and queries
+
+
+def _threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        return 4
+
+
+@pytest.mark.parametrize("dim", [128, 96])
+def test_gpu_answers_equal_the_faithful_tree_walk_at_a_million_rows(pn, oracle_mod, dim):
+    n, nq = 1_000_000, 96
+    pts = oracle_mod.fill_uniform(n * dim, SEED_P).reshape(n, dim)
+    qs = oracle_mod.fill_uniform(nq * dim, SEED_Q).reshape(nq, dim)
+    th = _threads()
+    walk = oracle_mod.Tree(pts, build_threads_log2=int(np.log2(th)))
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible
+    report = {}
+    for k in (10, 100):
+        wi, wd = walk.query_batch(qs, k, nthreads=th)
+        gi, gd = tree.query_batch(qs, k)                      # engine auto: what bench.py times
+        cmp = oracle_mod.compare_knn(wi, wd, gi, gd)
+        report[k] = cmp
+        assert cmp["agree"], f"D={dim} k={k}: faithful tree walk and GPU disagree outside exact ties: {cmp}"
+        # the walk evaluated far fewer than all rows only if it pruned: record what it did at this scale
+    cd, pd_ = walk.eval_counts()
+    # query_radius at a radius where about half of the lists are non-empty (bench.py --radius nn): the walk's lists
+    # (traversal order, sorted here as the reference's own tests do, src/ball_tree.rs:667,777) against the GPU's
+    nn = np.sort(tree.query_batch(qs, 1)[1][:, 0])
+    r = np.float32(float(nn[nq // 2]) * 1.0005)
+    off, ids = tree.query_radius_batch(qs, r)
+    differ = []
+    nonempty = 0
+    for a in range(nq):
+        want = np.sort(walk.query_radius(qs[a], r))
+        got = ids[int(off[a]):int(off[a + 1])]
+        nonempty += len(got) > 0
+        if not np.array_equal(got, want):
+            differ.append((a, want.tolist(), got.tolist()))
+    assert not differ, f"D={dim} r={r}: query_radius differs from the faithful walk on {len(differ)} queries: {differ[:3]}"
+    assert nq // 4 <= nonempty <= nq, nonempty
+    print(f"tree-vs-GPU at {n} x {dim}: k-NN {report}; radius r={r}: {nonempty}/{nq} non-empty lists, all equal; "
+          f"walk evaluated {cd} centroid + {pd_} point distances for {2 * nq} k-NN + {nq} radius queries")
+
+
+@pytest.mark.parametrize("n,dim,k", [(60_000, 16, 10), (200_000, 128, 10), (20_000, 3, 5)])
+def test_cosine_index_vs_the_reference_walk_under_cosine_records_the_deviation(pn, oracle_mod, n, dim, k):
+    """BallTree::new(points, Cosine): the reference walks its ball tree under a distance that is not a metric, so its
+    pruning (src/ball_tree.rs:212, 473-481) can skip true neighbours; this library's Cosine index returns the k smallest
+    Cosine::distance values whatever the tree would have pruned (documented deviation, include/petal_mi355x.h).  Where
+    the two differ the GPU's k-th distance must be the SMALLER one; the deviation rate is printed (and recorded in the
+    header comment of pn_index_create_cosine_*)."""
+    from conftest import uniform
+    from petal_neighbors_amd.distance import Cosine
+    pts = (uniform((n, dim), 9100 + dim) - np.float32(0.5)).astype(np.float32)
+    qs = (uniform((256, dim), 9200 + dim) - np.float32(0.5)).astype(np.float32)
+    walk = oracle_mod.Tree(pts, build_threads_log2=2, metric="cosine")
+    tree = pn.BallTree.new(pts, Cosine())
+    wi, wd = walk.query_batch(qs, k, nthreads=_threads())
+    gi, gd = tree.query_batch(qs, k)
+    same = (wd.view(np.uint32) == gd.view(np.uint32)).all(axis=1)
+    worse = 0
+    for a in np.nonzero(~same)[0]:
+        # every entry of the GPU's answer is at most the walk's entry of the same rank: the walk missed rows
+        assert (gd[a] <= wd[a]).all(), (a, gd[a], wd[a])
+        worse += 1
+    print(f"Cosine walk vs exact Cosine scan, {n} x {dim}, k={k}: the reference's walk misses a true neighbour on "
+          f"{worse} of {len(qs)} queries ({100.0 * worse / len(qs):.1f} %)")

@@ -150,8 +150,10 @@ class _CollectiveDouble:
     def __init__(self):
         self.built_with = None
 
-    def build_rank(self, rows, n_total, rank, world, comm_id):
+    def build_rank(self, rows, n_total, rank, world, comm_id, dtype=None):
         self.built_with = comm_id
+        self.dtype = dtype
+        self.rows = rows
 
 
 def _id_worker(rank, world, port, fail, out_dir):
@@ -192,3 +194,43 @@ def test_communicator_id_broadcast_is_failure_symmetric(tmp_path, fail):
         assert all(g.startswith("raised") for g in got), got
     else:
         assert got == ["built", "built"]
+
+
+def _dtype_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from petal_neighbors_amd import sharded
+        sharded.ShardedIndex.unique_id = staticmethod(lambda: bytes(range(128)))
+        eng = _CollectiveDouble()
+        outcome = "built"
+        try:
+            if case == "empty_rank_f64":   # 1 row over 2 ranks: rank 1 holds nothing and must still make an f64 handle
+                sharded.ShardedBallTree(1, lambda lo, hi: torch.zeros((hi - lo, 4), dtype=torch.float64), engine=eng,
+                                        dtype=np.float64)
+                outcome = "built %s rows=%s" % (np.dtype(eng.dtype).name, None if eng.rows is None else tuple(eng.rows.shape))
+            else:                          # rank 1 hands f32 rows to an f64 job: every rank raises, nobody hangs
+                dt = torch.float64 if rank == 0 else torch.float32
+                sharded.ShardedBallTree(100, lambda lo, hi: torch.zeros((hi - lo, 4), dtype=dt), engine=eng, dtype=np.float64)
+        except ValueError as e:
+            outcome = "raised: " + str(e)
+        with open(os.path.join(out_dir, f"dt{rank}.txt"), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["empty_rank_f64", "mismatch"])
+def test_ranks_agree_on_the_element_type(tmp_path, case):
+    """a rank without rows used to make an f32 handle whatever the other ranks held -- the packed parts of
+    the all-gather then differ in size between ranks.  The job's element type is now an argument, handed to every
+    rank's handle, and compared across the ranks before a communicator exists."""
+    port = _free_port()
+    mp.spawn(_dtype_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    got = [open(os.path.join(tmp_path, f"dt{r}.txt")).read() for r in range(2)]
+    if case == "empty_rank_f64":
+        assert got == ["built float64 rows=(1, 4)", "built float64 rows=None"], got
+    else:
+        assert all(g.startswith("raised: ShardedBallTree: the ranks do not agree") for g in got), got
