@@ -786,6 +786,66 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
 }
 
 // ---------------------------------------------------------------------------
+// Cosine indexes (round 4; SURVEY.md 8 f3: "normalise rows once, then the same contraction").  In real arithmetic
+// |q/|q| - p/|p||^2 = 2 (1 - cos(q, p)) = twice Cosine::distance, so the Euclidean bound over NORMALISED vectors orders
+// rows as the Cosine distance does.  This kernel writes the normalised rows in f64 -- x~_k = x_k * (1 / sqrt(sum x^2)),
+// every operation in f64 -- and everything downstream (column sums, row statistics, tile images, the query pack) is
+// the f64 instantiation of the Euclidean tier's kernels over them: the bound is a statement about these f64 vectors,
+// and select.hip (cos_proof_lb) accounts for what separates them from the reference's float arithmetic.
+// Eight lanes per row.  A row whose squared norm is not inside [2^-100, 2^100] (zero rows, non-finite coordinates: the
+// reference's distance is NaN or meaningless there) raises *bad (corpus: the index keeps the exact scan) or, nan_rows,
+// becomes a row of NaNs (queries: the pack kernel then flags that query for the exact engine).
+template <typename T>
+__global__ __launch_bounds__(256) void cos_normalize_rows_kernel(const T *__restrict__ X, size_t n_valid, size_t n_out,
+                                                                 int dim, size_t ld_in, double *__restrict__ out,
+                                                                 size_t ld_out, uint32_t *__restrict__ bad, int nan_rows) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = t >> 3;
+    const int sub = (int)(t & 7);
+    if (r >= n_out) return;  // (whole groups of eight leave together)
+    const int CH = (int)(ld_out / 8), c0 = sub * CH;
+    double *o = out + r * ld_out + c0;
+    if (r >= n_valid) {
+        for (int i = 0; i < CH; ++i) o[i] = 0.0;
+        return;
+    }
+    const T *x = X + r * ld_in;
+    double ss = 0.0;
+    for (int i = 0; i < CH; ++i)
+        if (c0 + i < dim) {
+            const double v = (double)x[c0 + i];
+            ss += v * v;
+        }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) ss += __shfl_xor(ss, d);
+    const bool ok = ss >= 7.888609052210118e-31 && ss <= 1.2676506002282294e30;  // 2^-100 .. 2^100 (false for NaN)
+    if (!ok) {
+        if (nan_rows) {
+            for (int i = 0; i < CH; ++i) o[i] = (c0 + i < dim) ? __longlong_as_double(0x7FF8000000000000ll) : 0.0;
+        } else {
+            if (sub == 0) atomicOr(bad, 1u);
+            for (int i = 0; i < CH; ++i) o[i] = 0.0;
+        }
+        return;
+    }
+    const double inv = 1.0 / sqrt(ss);
+    for (int i = 0; i < CH; ++i) o[i] = (c0 + i < dim) ? (double)x[c0 + i] * inv : 0.0;
+}
+template <typename T>
+hipError_t launch_cos_normalize_rows(const T *X, size_t n_valid, size_t n_out, int dim, size_t ld_in, double *out,
+                                     size_t ld_out, uint32_t *bad, bool nan_rows, hipStream_t s) {
+    if (ld_out % 8 != 0 || (size_t)dim > ld_out || (size_t)dim > ld_in) return hipErrorInvalidValue;
+    const size_t threads = n_out * 8;
+    hipLaunchKernelGGL((cos_normalize_rows_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, X, n_valid,
+                       n_out, dim, ld_in, out, ld_out, bad, nan_rows ? 1 : 0);
+    return hipGetLastError();
+}
+template hipError_t launch_cos_normalize_rows<float>(const float *, size_t, size_t, int, size_t, double *, size_t, uint32_t *,
+                                                     bool, hipStream_t);
+template hipError_t launch_cos_normalize_rows<double>(const double *, size_t, size_t, int, size_t, double *, size_t, uint32_t *,
+                                                      bool, hipStream_t);
+
+// ---------------------------------------------------------------------------
 // compaction of one query's buffer (<= 64*M entries in HBM) by its wave: keep the kp smallest under
 // (key, row); returns the kp-th key T and the new count (wave-uniform).  Same radix select as
 // compact_query (topk_buffer.h) but the bookkeeping goes back to registers.
@@ -2670,6 +2730,33 @@ hipError_t launch_bf16_column_sums(const T *P, size_t n, int dim, size_t ld, dou
 }
 template hipError_t launch_bf16_column_sums<float>(const float *, size_t, int, size_t, double *, hipStream_t);
 template hipError_t launch_bf16_column_sums<double>(const double *, size_t, int, size_t, double *, hipStream_t);
+
+// The translation vector, decided on the device (round 4: finish_index read the sums back and decided on the host -- one
+// of six stream synchronisations of an index build).  sums = bf16_column_sums_kernel's output (dim column sums, then the
+// sum of all squares): mu = the per-dimension mean as f32, kept when translating shrinks the sum of squared norms by
+// `factor` (16; wide rows 2: DESIGN.md 4.0b), else zero.  words[0] = 1 when the corpus is translated.  One thread.
+__global__ void bf16_decide_mu_kernel(const double *__restrict__ sums, size_t n, int dim, double factor, int never,
+                                      float *__restrict__ mu, uint32_t *__restrict__ words) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double mu2 = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        const double m = sums[k] / (double)n;
+        const float f = (m == m && fabs(m) < 1e30) ? (float)m : 0.0f;
+        mu[k] = f;
+        mu2 += (double)f * (double)f;
+    }
+    // sum |p - mu|^2 = sum |p|^2 - n |mu|^2
+    const double s2 = sums[dim], s2c = s2 - (double)n * mu2;
+    const bool centered = !never && s2 > 0.0 && s2c < s2 / factor;
+    if (!centered)
+        for (int k = 0; k < dim; ++k) mu[k] = 0.0f;
+    words[0] = centered ? 1u : 0u;
+}
+hipError_t launch_bf16_decide_mu(const double *sums, size_t n, int dim, bool never, float *mu, uint32_t *words, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_decide_mu_kernel, dim3(1), dim3(64), 0, s, sums, n, dim, bf16_is_wide(dim) ? 2.0 : 16.0,
+                       never ? 1 : 0, mu, words);
+    return hipGetLastError();
+}
 
 template <typename T>
 hipError_t launch_bf16_row_stats(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out4,

@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void exact_knn_kernel(
         if (COS) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                qn4[a] = qnorm[q0 + qb + a];
+                // (with a selection list the norms are indexed like the rows of Q: by the listed query number)
+                const size_t qi = q0 + qb + a;
+                qn4[a] = qsel_t ? (qi < (size_t)nq ? qnorm[qsel_t[qb + a]] : (T)1) : qnorm[qi];
                 pn4[a] = pnorm[p0 + pb + a];
             }
         }
@@ -274,7 +276,6 @@ static hipError_t launch_exact_knn(const T *P, size_t n, int dim, size_t ldp, co
                                    const uint32_t *lo_idx, const uint32_t *nq_dev, uint32_t nq_off, const T *pnorm,
                                    const T *qnorm, hipStream_t s, const uint32_t *qsel = nullptr) {
     using KeyT = typename KeyOf<T>::type;
-    if (qsel && pnorm) return hipErrorInvalidValue;  // (the selection list serves the Euclidean second tier only)
     dim3 grid((unsigned)(cb.nq_pad / kTileQ), (unsigned)cb.nseg), block(256);
     const bool cosm = pnorm != nullptr;
     auto *ck = static_cast<KeyT *>(cb.keys);

@@ -115,10 +115,10 @@ hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t
                                    hipStream_t s, const uint32_t *osel = nullptr);
 hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, float *dist_out, size_t out_group_stride,
-                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s, bool signed_keys = false);
 hipError_t launch_select_exact_groups_f64(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, double *dist_out, size_t out_group_stride,
-                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s);
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s, bool signed_keys = false);
 // MFMA mode: keys are f32 lower bounds L; recomputes every candidate's distance
 // in the reference's operation order, selects, and verifies the filter's
 // exclusions (flags[q] = 1 -> the query must be re-run exactly).
@@ -143,6 +143,18 @@ hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n
                                     uint64_t *idx_out, double *dist_out, size_t out_stride, uint32_t *flags,
                                     uint32_t *n_flagged, const double *qn, const uint32_t *qbad, uint32_t *sel,
                                     unsigned long long *stats, hipStream_t s, int first_eval = 0, int cell_max = 0);
+// Cosine indexes behind the bf16 filter (select.hip, cos_proof_lb): cnorm [n] / qnorm [nq] = the rows' / queries' norms in
+// the index's type (cosine_norms_kernel), candidates evaluated by Cosine::distance, order-preserving keys of ALL floats
+hipError_t launch_select_rerank_cos_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp, const float *Q,
+                                        int nq, size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                        float *dist_out, size_t out_stride, uint32_t *flags, uint32_t *n_flagged,
+                                        const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *stats,
+                                        hipStream_t s, int first_eval, int cell_max, const float *cnorm, const float *qnorm);
+hipError_t launch_select_rerank_cos_f64(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp, const double *Q,
+                                        int nq, size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                        double *dist_out, size_t out_stride, uint32_t *flags, uint32_t *n_flagged,
+                                        const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *stats,
+                                        hipStream_t s, int first_eval, int cell_max, const double *cnorm, const double *qnorm);
 // osel (nullable): the merged result of query q goes to row osel[q] of the outputs (row stride out_stride, 0 = k_out);
 // host_count (nullable, mapped pinned memory): block 0 copies *nq_dev there (the count a LATER call looks at)
 // Small corpora, a few queries per call: the whole call in one launch (one wave per query over all rows); Q and the
@@ -241,10 +253,18 @@ int bf16_query_tile();                             // queries per workgroup (256
 // (zeroed by the caller)
 template <typename T>  // T = float | double (explicitly instantiated): the index's element type
 hipError_t launch_bf16_column_sums(const T *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
+// mu [dim] <- the per-dimension mean (f32) when translating by it shrinks the sum of squared norms 16x (wide rows: 2x), else
+// zero; words[0] <- 1 / 0 accordingly.  never: always zero (diagnostic builds)
+hipError_t launch_bf16_decide_mu(const double *sums, size_t n, int dim, bool never, float *mu, uint32_t *words, hipStream_t s);
 // out4 (zeroed by the caller): max Bp, max Dp, sum Bp, sum Dp over the rows
 template <typename T>
 hipError_t launch_bf16_row_stats(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out4,
                                  hipStream_t s);
+// Cosine indexes: rows normalised in f64 (bf16_filter.hip, cos_normalize_rows_kernel); out [n_out][ld_out], rows >= n_valid
+// zero; a row with a squared norm outside [2^-100, 2^100] raises *bad, or (nan_rows) becomes NaNs
+template <typename T>
+hipError_t launch_cos_normalize_rows(const T *X, size_t n_valid, size_t n_out, int dim, size_t ld_in, double *out,
+                                     size_t ld_out, uint32_t *bad, bool nan_rows, hipStream_t s);
 template <typename T>
 hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int dim, size_t ld, void *img,
                                    uint32_t *bad, bool ci, hipStream_t s);

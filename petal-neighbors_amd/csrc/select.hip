@@ -205,15 +205,15 @@ static hipError_t launch_select_exact(const CandBuf &cb, int nq, int kout, uint6
 // kp: entries a cell holds at most (the scan kernel's final compaction leaves <= its kp)
 hipError_t launch_select_exact_groups_f32(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, float *dist_out, size_t out_group_stride,
-                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s, bool signed_keys) {
     return launch_select_exact<float>(cb, nq, kout, index_base, idx_out, dist_out, kp, (size_t)kout, 0, nullptr, nullptr,
-                                      nq_dev, nq_off, false, s, groups, out_group_stride);
+                                      nq_dev, nq_off, signed_keys, s, groups, out_group_stride);
 }
 hipError_t launch_select_exact_groups_f64(const CandBuf &cb, int groups, int kp, int nq, int kout, uint64_t index_base,
                                           uint64_t *idx_out, double *dist_out, size_t out_group_stride,
-                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s) {
+                                          const uint32_t *nq_dev, uint32_t nq_off, hipStream_t s, bool signed_keys) {
     return launch_select_exact<double>(cb, nq, kout, index_base, idx_out, dist_out, kp, (size_t)kout, 0, nullptr, nullptr,
-                                       nq_dev, nq_off, false, s, groups, out_group_stride);
+                                       nq_dev, nq_off, signed_keys, s, groups, out_group_stride);
 }
 hipError_t launch_select_exact_f32(const CandBuf &cb, int nq, int kout, uint64_t index_base, uint64_t *idx_out,
                                    float *dist_out, size_t out_stride, size_t out_off, void *lo_key,
@@ -430,6 +430,53 @@ template <> __device__ __forceinline__ double proof_lb<double>(double L, double 
                (1.0 - 8.881784197001252e-16) - 1e-300;
 }
 
+// ---- Cosine indexes behind the bf16 filter (round 4).  The filter ran on the rows and queries NORMALISED in f64
+// (p~ = p / |p|, q~ = q / |q|: index.hip) and bounds |q~ - p~|^2, which in real arithmetic is 2 (1 - cos) = twice the
+// Cosine distance; the candidates are evaluated here in the REFERENCE's arithmetic (src/distance.rs:85-107: dot, the two
+// squared norms each a sequential fold of separately rounded products, norm1 * norm2, one division, one subtraction),
+// with |p| from the index (cosine_norms_kernel: the same fold) and |q| from the call's query norms.
+template <typename T>
+__device__ __forceinline__ T exact_cosine_prefetched(const T *qs, const T *__restrict__ p, int len, T qnorm, T pnorm) {
+#pragma clang fp contract(off)
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T tv_ __attribute__((ext_vector_type(VE)));
+    T dot = (T)0;
+    for (int k0 = 0; k0 < len; k0 += 16 * VE) {  // 16 independent 16-byte loads in flight per round (len a multiple of 8)
+        tv_ v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (k0 + VE * i < len) v[i] = *reinterpret_cast<const tv_ *>(p + k0 + VE * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (k0 + VE * i < len) {
+                const tv_ a = *reinterpret_cast<const tv_ *>(qs + k0 + VE * i);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    const T pr = a[j] * v[i][j];  // (zero padding: + 0 changes nothing)
+                    dot = dot + pr;
+                }
+            }
+        }
+    }
+    const T den = qnorm * pnorm;
+    return (T)1 - dot / den;
+}
+// Lower bound of the REFERENCE's Cosine::distance d_ref(q, p) for a row whose (tagged) filter bound is L, qadd <= |q~|^2
+// (minus E(q) in the CI layout), D = dim, u = the type's unit roundoff:
+//   |q~ - p~|^2 >= (L - |L| 2^-19) + qadd                                   (the filter's guarantee, as for Euclidean)
+//   | |q~ - p~|^2 - 2 d* | <= eps1 = (4.5 D + 45) 2^-53                      (d* = 1 - cos in real arithmetic; q~, p~ are
+//        the f64-computed normalisations: every coordinate within (D/2 + 5) 2^-53 relative of q_k / |q|)
+//   | d_ref - d* | <= E' = (2 D + 16) u                                     (dot: gamma_D |q||p|; the norms' folds and sqrt,
+//        their product, the division, the subtraction; norms^2 in [2^-100, 2^100] keep underflow below D 2^-50 u)
+// so d_ref >= ((L - |L| 2^-19) + qadd - eps1) / 2 - E', evaluated in f64 and pushed down for its own roundings.
+template <typename T> __device__ __forceinline__ double cos_proof_lb(double L, double qadd, int dim) {
+    const double u = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+    const double x = (L - fabs(L) * 1.9073486328125e-06) + qadd;
+    const double eps1 = (4.5 * (double)dim + 45.0) * 1.1102230246251565e-16;
+    const double e = (2.0 * (double)dim + 16.0) * u;
+    return 0.5 * (x - eps1) - e - (fabs(x) + 1.0) * 1.0e-15;
+}
+
 #ifdef PN_DIAG_RR_STAMP  // diagnostic build only: where a re-rank wave's time goes (cycle sums per phase)
 // per-query phase durations [16384][8], written once per wave at its end (an atomic per phase on a shared counter
 // would itself be what the waves wait for)
@@ -455,7 +502,7 @@ extern "C" int pn_debug_read_rr(unsigned long long *out, int nq) {
 #ifndef PN_DIAG_RR_WAVES
 #define PN_DIAG_RR_WAVES 1
 #endif
-template <typename T>
+template <typename T, bool COS = false>
 __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
     const uint32_t *__restrict__ ctau, const uint32_t *__restrict__ cidx, const uint32_t *__restrict__ ccnt,
     size_t nq_pad, int nseg, int cap, const T *__restrict__ P, size_t ldp, const T *__restrict__ Q,
@@ -463,10 +510,17 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
     T *__restrict__ dist_out, size_t out_stride, uint32_t *__restrict__ flags, uint32_t *__restrict__ n_flagged,
     const double *__restrict__ qn, const uint32_t *__restrict__ qbad,
     int idx_stride, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ sel,
-    unsigned long long *__restrict__ stats, uint32_t first_eval) {
+    unsigned long long *__restrict__ stats, uint32_t first_eval, const T *__restrict__ cnorm = nullptr,
+    const T *__restrict__ qnorm = nullptr) {
+    // COS: a Cosine index (cnorm = the rows' norms, qnorm = the queries'): candidates are evaluated by Cosine::distance,
+    // keys are the order-preserving map of ALL floats (a distance can lie a few ulp below zero), the proof is cos_proof_lb
     using KeyT = typename KeyOf<T>::type;
     constexpr KeyT KMAX = KeyOf<T>::kMax;                       // an entry whose distance has not been evaluated
-    const KeyT KINF = sel_key((T)__builtin_huge_val());        // key of +inf: keys at or above it are inf / NaN
+    const KeyT KINF = COS ? sel_key_signed((T)__builtin_huge_val()) : sel_key((T)__builtin_huge_val());  // keys at or above it are inf / NaN
+    auto eval_row = [&](const T *qv, uint32_t ix, int ln) -> KeyT {
+        if constexpr (COS) return sel_key_signed(exact_cosine_prefetched<T>(qv, P + (size_t)ix * ldp, ln, qnorm[blockIdx.x], cnorm[ix]));
+        else return sel_key(exact_distance_prefetched<T>(qv, P + (size_t)ix * ldp, ln));
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ KeyT kth_key;
     __shared__ uint32_t seg_off[65], seg_cnt[64];
@@ -633,7 +687,7 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
                     const uint32_t e = elist[lane];
                     const uint32_t ix = sidx[e];
                     if (ix < n_rows) {
-                        lane_key = sel_key(exact_distance_prefetched<T>(qs, P + (size_t)ix * ldp, len));
+                        lane_key = eval_row(qs, ix, len);
                         skey[e] = lane_key;
                     }
                 }
@@ -659,7 +713,7 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
             RR_STAMP(4);  // k-th smallest exact distance so far
             const bool prune = dk1 < KINF;  // finite: else every candidate is evaluated
             double rhs = 0.0;
-            if (prune) rhs = proof_rhs<T>(dk1);
+            if (prune) rhs = COS ? (double)key_to_dist_signed(dk1) : proof_rhs<T>(dk1);
             const double qadd = qn ? qn[q] : 0.0;
             // (the first round evaluated exactly the entries with a bound <= K1: the rest are the unevaluated ones)
             eval_packed([&](uint32_t e) {
@@ -668,7 +722,8 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
                 if (fk <= K1) return false;
                 if (!prune) return true;
                 const double L = (double)__uint_as_float((fk & 0x80000000u) ? (fk & 0x7FFFFFFFu) : ~fk);
-                return !(proof_lb<T>(L, qadd, dim) > rhs);  // not provably farther than the kout-th exact distance so far
+                // not provably farther than the kout-th exact distance so far
+                return !((COS ? cos_proof_lb<T>(L, qadd, dim) : proof_lb<T>(L, qadd, dim)) > rhs);
             });
         }
     }
@@ -704,7 +759,7 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
         const uint32_t r = rank_of<KeyT, uint32_t>(skey, sidx, n, k, ix);
         if (r < (uint32_t)kout) {
             idx_out[q * out_stride + r] = index_base + ix;
-            dist_out[q * out_stride + r] = key_to_dist(k);
+            dist_out[q * out_stride + r] = COS ? key_to_dist_signed(k) : key_to_dist(k);
             if (r == (uint32_t)kout - 1) kth_key = k;
         }
     }
@@ -723,12 +778,17 @@ __global__ __launch_bounds__(64, PN_DIAG_RR_WAVES) void select_rerank_kernel(
         const KeyT kk = kth_key;
         if (ok && kk >= KINF) ok = false;  // k-th distance is inf/NaN: let the exact engine order it
         if (ok && min_tau < __uint_as_float(0x7F800000u)) {
-            const double rhs = proof_rhs<T>(kk);
-            // bf16 filter: the thresholds are TAGGED bounds of d2 - |q|^2 (bf16_filter.hip): within 2^-19 relative
-            // of the bound itself; qn[q] <= |q|^2
-            const double lb = qn ? proof_lb<T>((double)min_tau, qn[q], dim)
-                                 : (double)min_tau * (1.0 - (double)(dim + 4) * u) - 1e-37;
-            ok = (min_tau == min_tau) && (lb > rhs);
+            if constexpr (COS) {
+                // every dropped row's reference distance is >= lb; strictly above the k-th one found: it cannot tie either
+                ok = (min_tau == min_tau) && qn && (cos_proof_lb<T>((double)min_tau, qn[q], dim) > (double)key_to_dist_signed(kk));
+            } else {
+                const double rhs = proof_rhs<T>(kk);
+                // bf16 filter: the thresholds are TAGGED bounds of d2 - |q|^2 (bf16_filter.hip): within 2^-19 relative
+                // of the bound itself; qn[q] <= |q|^2
+                const double lb = qn ? proof_lb<T>((double)min_tau, qn[q], dim)
+                                     : (double)min_tau * (1.0 - (double)(dim + 4) * u) - 1e-37;
+                ok = (min_tau == min_tau) && (lb > rhs);
+            }
         }
         if (qbad && qbad[q]) ok = false;
         flags[q] = ok ? 0u : 1u;
@@ -752,7 +812,7 @@ static hipError_t launch_select_rerank(const CandBuf &cb, const T *P, size_t n, 
                                        size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out, T *dist_out,
                                        size_t out_stride, uint32_t *flags, uint32_t *n_flagged, const double *qn,
                                        const uint32_t *qbad, uint32_t *sel, unsigned long long *stats, hipStream_t s,
-                                       int first_eval, int cell_max) {
+                                       int first_eval, int cell_max, const T *cnorm = nullptr, const T *qnorm = nullptr) {
     using KeyT = typename KeyOf<T>::type;
     // with filter keys in the buffers (both MFMA tiers) candidates are evaluated lazily
     const uint32_t *ckey = static_cast<const uint32_t *>(cb.keys);
@@ -761,10 +821,19 @@ static hipError_t launch_select_rerank(const CandBuf &cb, const T *P, size_t n, 
     const size_t per_cell = cell_max > 0 && cell_max < cb.cap ? (size_t)cell_max : (size_t)cb.cap;
     const size_t sh = (size_t)cb.nseg * per_cell * (sizeof(KeyT) + 8) + ((size_t)dim + 8) * sizeof(T);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_rerank_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s,
+    if (cnorm) {  // a Cosine index: the bf16 filter's (key, row) pairs only
+        if (!ckey || !qnorm || !qn) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((select_rerank_kernel<T, true>), dim3((unsigned)nq), dim3(64), sh, s,
+                           static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
+                           ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, out_stride, flags, n_flagged, qn,
+                           qbad, cb.idx_stride, ckey, sel, stats, (uint32_t)(first_eval > 0 ? first_eval : 0), cnorm, qnorm);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((select_rerank_kernel<T, false>), dim3((unsigned)nq), dim3(64), sh, s,
                        static_cast<const uint32_t *>(cb.tau), cb.idx, cb.cnt, cb.nq_pad, cb.nseg, cb.cap, P, ldp, Q,
                        ldq, dim, (uint32_t)n, kout, index_base, idx_out, dist_out, out_stride, flags, n_flagged, qn,
-                       qbad, cb.idx_stride, ckey, sel, stats, (uint32_t)(first_eval > 0 ? first_eval : 0));
+                       qbad, cb.idx_stride, ckey, sel, stats, (uint32_t)(first_eval > 0 ? first_eval : 0), (const T *)nullptr,
+                       (const T *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_select_rerank_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp,
@@ -784,6 +853,24 @@ hipError_t launch_select_rerank_f64(const CandBuf &cb, const double *P, size_t n
     if (!qn) return hipErrorInvalidValue;  // (only the bf16 tier serves f64)
     return launch_select_rerank<double>(cb, P, n, dim, ldp, Q, nq, ldq, kout, index_base, idx_out, dist_out, out_stride,
                                         flags, n_flagged, qn, qbad, sel, stats, s, first_eval, cell_max);
+}
+// Cosine indexes behind the bf16 filter: candidates evaluated by Cosine::distance (cnorm / qnorm: the rows' and the queries'
+// norms in the index's type), signed keys, cos_proof_lb
+hipError_t launch_select_rerank_cos_f32(const CandBuf &cb, const float *P, size_t n, int dim, size_t ldp, const float *Q,
+                                        int nq, size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                        float *dist_out, size_t out_stride, uint32_t *flags, uint32_t *n_flagged,
+                                        const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *stats,
+                                        hipStream_t s, int first_eval, int cell_max, const float *cnorm, const float *qnorm) {
+    return launch_select_rerank<float>(cb, P, n, dim, ldp, Q, nq, ldq, kout, index_base, idx_out, dist_out, out_stride,
+                                       flags, n_flagged, qn, qbad, sel, stats, s, first_eval, cell_max, cnorm, qnorm);
+}
+hipError_t launch_select_rerank_cos_f64(const CandBuf &cb, const double *P, size_t n, int dim, size_t ldp, const double *Q,
+                                        int nq, size_t ldq, int kout, uint64_t index_base, uint64_t *idx_out,
+                                        double *dist_out, size_t out_stride, uint32_t *flags, uint32_t *n_flagged,
+                                        const double *qn, const uint32_t *qbad, uint32_t *sel, unsigned long long *stats,
+                                        hipStream_t s, int first_eval, int cell_max, const double *cnorm, const double *qnorm) {
+    return launch_select_rerank<double>(cb, P, n, dim, ldp, Q, nq, ldq, kout, index_base, idx_out, dist_out, out_stride,
+                                        flags, n_flagged, qn, qbad, sel, stats, s, first_eval, cell_max, cnorm, qnorm);
 }
 
 // ---------------------------------------------------------------------------
