@@ -269,17 +269,25 @@ def bench_f64(args):
     from petal_neighbors_amd import _lib
     torch.cuda.set_device(0)
     n, dim, nq, k = CONFIGS[args.config]
-    # f64 coordinates with more than 24 significant bits: two f32 draws, the second scaled by 2^-24
-    pts = (oracle.fill_uniform(n * dim, SEED_P).astype(np.float64) +
-           oracle.fill_uniform(n * dim, SEED_P + 7).astype(np.float64) * 2.0 ** -24).reshape(n, dim)
-    qs = (oracle.fill_uniform(nq * dim, SEED_Q).astype(np.float64) +
-          oracle.fill_uniform(nq * dim, SEED_Q + 7).astype(np.float64) * 2.0 ** -24).reshape(nq, dim)
-    tree = pn.BallTree.euclidean(pts)
+    cosine = args.metric == "cosine"
+    f64 = args.dtype == "f64"
+    if f64:  # f64 coordinates with more than 24 significant bits: two f32 draws, the second scaled by 2^-24
+        pts = (oracle.fill_uniform(n * dim, SEED_P).astype(np.float64) +
+               oracle.fill_uniform(n * dim, SEED_P + 7).astype(np.float64) * 2.0 ** -24).reshape(n, dim)
+        qs = (oracle.fill_uniform(nq * dim, SEED_Q).astype(np.float64) +
+              oracle.fill_uniform(nq * dim, SEED_Q + 7).astype(np.float64) * 2.0 ** -24).reshape(nq, dim)
+    else:
+        pts = oracle.fill_uniform(n * dim, SEED_P).reshape(n, dim)
+        qs = oracle.fill_uniform(nq * dim, SEED_Q).reshape(nq, dim)
+    if cosine:  # uniform [-0.5, 0.5): directions spread over the whole sphere (all-positive data sits in a narrow cone)
+        pts = (pts - pts.dtype.type(0.5)).astype(pts.dtype)
+        qs = (qs - qs.dtype.type(0.5)).astype(qs.dtype)
+    tree = pn.BallTree.new(pts, pn.distance.Cosine()) if cosine else pn.BallTree.euclidean(pts)
     tree.set_engine(args.engine)
     tree.set_option(_lib.PN_OPT_PROFILE, 1)
     qd = torch.from_numpy(qs).to("cuda:0")
     out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device="cuda:0")
-    out_dst = torch.empty((nq, min(k, n)), dtype=torch.float64, device="cuda:0")
+    out_dst = torch.empty((nq, min(k, n)), dtype=torch.float64 if f64 else torch.float32, device="cuda:0")
     for _ in range(args.warmup):
         tree.query_device(qd, k, out_idx, out_dst)
     torch.cuda.synchronize()
@@ -299,17 +307,36 @@ def bench_f64(args):
             verified["ok"] = verified["ok"] and bool(ok)
         gi, gd = out_idx.cpu().numpy(), out_dst.cpu().numpy()
         chk("ascending", bool((gd[:, 1:] >= gd[:, :-1]).all()) if gd.shape[1] > 1 else True)
-        sel = np.linspace(0, nq - 1, 32).astype(np.int64)
-        wi, wd = oracle.brute_knn(pts, qs[sel], k)
-        chk("oracle f64 brute force on 32 sampled queries",
-            np.array_equal(gi[sel].astype(np.uint64), wi) and gd[sel].tobytes() == wd.tobytes())
+        if cosine:
+            # the oracle's scalar Cosine::distance over a shortlist of the 400 rows of largest f64 cosine (the float
+            # result is within 1e-4 of the real cosine; the shortlist's tail is far beyond the k-th), (distance, index) order
+            sel = np.linspace(0, nq - 1, 16).astype(np.int64)
+            pn64 = pts.astype(np.float64)
+            pn64 /= np.linalg.norm(pn64, axis=1, keepdims=True)
+            ok = True
+            for a in sel:
+                c = pn64 @ (qs[a].astype(np.float64) / np.linalg.norm(qs[a].astype(np.float64)))
+                short = np.argpartition(-c, 400)[:400]
+                d = np.array([oracle.cosine(qs[a], pts[i]) for i in short], dtype=pts.dtype)
+                order = np.lexsort((short, d))[:k]
+                ok = ok and np.array_equal(gi[a].astype(np.int64), short[order]) and gd[a].tobytes() == d[order].tobytes()
+            del pn64
+            chk("oracle Cosine::distance on 16 sampled queries (shortlist of 400 by f64 cosine)", ok)
+        else:
+            sel = np.linspace(0, nq - 1, 32).astype(np.int64)
+            wi, wd = oracle.brute_knn(pts, qs[sel], k)
+            chk("oracle brute force on 32 sampled queries",
+                np.array_equal(gi[sel].astype(np.uint64), wi) and gd[sel].tobytes() == wd.tobytes())
         ne = min(nq, 1024)
         esel = torch.linspace(0, nq - 1, ne, device="cuda:0").long()
         tree.set_engine("exact")
+        t_e0 = time.perf_counter()
         ei, ed = tree.query_device(qd[esel].contiguous(), k)
         torch.cuda.synchronize()
-        chk(f"exact f64 engine on {ne} queries", torch.equal(ei, out_idx[esel]) and
-            torch.equal(ed.view(torch.int64), out_dst[esel].view(torch.int64)))
+        exact_ms_per_query = (time.perf_counter() - t_e0) * 1e3 / ne
+        iv = torch.int64 if f64 else torch.int32
+        chk(f"exact engine on {ne} queries", torch.equal(ei, out_idx[esel]) and
+            torch.equal(ed.view(iv), out_dst[esel].view(iv)))
     launches = max(int(st["hot_launches"]), 1)
     hot_ms = st["hot_ms"] / launches
     flops_per_launch = 2.0 * n * dim * nq * args.steps / launches
@@ -318,14 +345,18 @@ def bench_f64(args):
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     ms_per_step = elapsed / args.steps * 1e3
     kernel_name = ("bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel") if bf else "exact_knn_kernel"
-    traffic, traffic_src = committed_traffic(kernel_name, args.config + "_f64")
+    tag = ("_f64" if f64 else "") + ("_cosine" if cosine else "")
+    traffic, traffic_src = committed_traffic(kernel_name, args.config + tag)
+    ty = "fp64" if f64 else "fp32"
     line = {
-        "metric": f"exact k-NN queries/sec ({n} x {dim} fp64, k={k})", "value": round(nq * args.steps / elapsed, 1),
+        "metric": f"exact {'Cosine ' if cosine else ''}k-NN queries/sec ({n} x {dim} {ty}, k={k})",
+        "value": round(nq * args.steps / elapsed, 1),
         "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config} f64: {n} points x {dim} dims f64, {nq} queries, k={k}, uniform[0,1) with 48 "
-                               f"random bits", "n_points": n, "dim": dim, "n_queries": nq, "k": k,
-                   "engine": "bf16 filter + f64 re-rank" if bf else "exact f64 scan"},
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if f64 else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}{tag.replace('_', ' ')}: {n} points x {dim} dims {ty}, {nq} queries, k={k}, "
+                               + ("uniform[-0.5,0.5), BallTree::new(points, Cosine)" if cosine else "uniform[0,1) with 48 random bits"),
+                   "n_points": n, "dim": dim, "n_queries": nq, "k": k, "metric": "Cosine" if cosine else "Euclidean",
+                   "engine": (f"bf16 filter + {'Cosine::distance' if cosine else ty} re-rank") if bf else "exact scan"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
                      **({"traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})"}
@@ -339,6 +370,8 @@ def bench_f64(args):
         "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
         "exact_evaluations_per_query": round(st["evaluations"] / max(st["queries"], 1), 2),
     }
+    if not args.no_verify:  # the exact scan on the verification sample, for scale (one un-warmed call: an upper bound)
+        line["exact_scan_ms_per_query_1024"] = round(exact_ms_per_query, 5)
     emit(line)
 
 
@@ -444,6 +477,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the parity leg (outside the timed region)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="f64: the k-NN step on an f64 index (bf16 filter + f64 re-rank), one GPU")
+    ap.add_argument("--metric", default="euclidean", choices=["euclidean", "cosine"],
+                    help="cosine: BallTree::new(points, Cosine) -- bf16 filter over the normalised rows + Cosine::distance "
+                         "re-rank (one GPU, index built through the host API)")
     ap.add_argument("--mode", default="knn", choices=["knn", "radius"],
                     help="radius: BallTree::query_radius over the batch (host queries in, host CSR out), one GPU")
     ap.add_argument("--radius", default="0.5",
@@ -470,9 +506,9 @@ def main():
 
     if args.config == "c1":
         return plumbing(args)
-    if args.dtype == "f64":
+    if args.dtype == "f64" or args.metric == "cosine":
         if args.gpus != 1 or args.mode != "knn":
-            sys.exit("bench.py: --dtype f64 is the one-GPU k-NN step")
+            sys.exit("bench.py: --dtype f64 / --metric cosine are the one-GPU k-NN step")
         return bench_f64(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
