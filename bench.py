@@ -487,6 +487,8 @@ def main():
                          "of the queries x 1.0005, so that about half of the lists are non-empty")
     ap.add_argument("--shared-thresholds", type=int, default=-1,
                     help="PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto (library default), >= 2 the rank itself")
+    ap.add_argument("--waves", type=int, default=0, choices=[0, 4, 8],
+                    help="PN_OPT_BF16_WAVES: 0 = library default (by run length), 4 / 8 = force that main-pass kernel")
     ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
                     help="abi: the all-gather is RCCL behind the C ABI (pn_sharded_*); torch: torch.distributed")
     args = ap.parse_args()
@@ -582,6 +584,8 @@ def main():
             tree.set_option(_lib.PN_OPT_EXCHANGE_ALWAYS, 1)  # rehearsal of the N > 1 path on one GPU (tests)
         if args.shared_thresholds >= 0:
             tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, args.shared_thresholds)
+        if args.waves:
+            tree.set_option(_lib.PN_OPT_BF16_WAVES, args.waves)
         tree.set_option(_lib.PN_OPT_PROFILE, 1)
     n_local = index.n_local
     out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device=dev)

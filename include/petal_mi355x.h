@@ -89,11 +89,16 @@ enum {
     PN_OPT_EXCHANGE_ALWAYS = 7, /* pn_sharded_set_option only.  A handle with ONE shard answers straight into the
                                   caller's buffers (nothing to exchange); 1 sends it through the packed buffer, the
                                   all-gather and the merge all the same (tests: RCCL at world size 1) */
-    PN_OPT_SHARED_THRESHOLDS = 8 /* bf16 tier, plans with several row segments per query: 1 (default) = the segments
+    PN_OPT_SHARED_THRESHOLDS = 8, /* bf16 tier, plans with several row segments per query: 1 (default) = the segments
                                   of a query tighten each other's thresholds while the filter runs (refresher
                                   workgroups in the idle workgroup slots); 0 = off; n >= 2 = on with the shared
                                   threshold at the n-th smallest bound of the union (experiments).  Never changes a
                                   result: only how many candidates the filter keeps. */
+    PN_OPT_BF16_WAVES = 9        /* bf16 tier, narrow rows, main pass of a k-NN call: 0 (default) = the library picks -- the
+                                  8-wave kernel (one 32-query column block per wave, four waves per SIMD) for short runs,
+                                  the 4-wave kernel (two column blocks per wave, two waves per SIMD) for long ones; 4 / 8
+                                  = always that kernel where it applies.  Never changes a result (A/B measurements,
+                                  tests of both kernels). */
 };
 
 typedef struct pn_index pn_index;
@@ -212,6 +217,18 @@ int pn_query_radius_f32(const pn_index *index, const float *queries, size_t nq, 
 int pn_query_radius_f64(const pn_index *index, const double *queries, size_t nq, size_t q_cols,
                         ptrdiff_t q_row_stride, double radius, uint64_t *offsets, uint64_t **idx_out);
 void pn_free(void *p);
+/* The same for queries ALREADY IN HBM (round 4), everything enqueued on `stream`, nothing read back: the caller supplies
+ * d_idx and its capacity (entries).  d_offsets [nq + 1] always receives the complete CSR offsets (per-query counts scanned
+ * on the device); the rows of query q land at d_idx[d_offsets[q] ...] wherever that position is below `capacity`; and
+ * d_total[0] (nullable) = d_offsets[nq].  A total above the capacity means "call again with a larger buffer" -- every
+ * offset is right and the first `capacity` entries are in place even then; capacity = 0 (d_idx may be NULL) only counts.
+ * Same lists, same order as pn_query_radius_* (strict '<', ascending index).  q_row_stride in elements. */
+int pn_query_radius_device_f32(const pn_index *index, const float *d_queries, size_t nq, size_t q_cols,
+                               size_t q_row_stride, float radius, uint64_t *d_offsets, uint64_t *d_idx, size_t capacity,
+                               uint64_t *d_total, void *stream);
+int pn_query_radius_device_f64(const pn_index *index, const double *d_queries, size_t nq, size_t q_cols,
+                               size_t q_row_stride, double radius, uint64_t *d_offsets, uint64_t *d_idx, size_t capacity,
+                               uint64_t *d_total, void *stream);
 
 /* ---- distance::pairwise(x, &Euclidean) (src/distance.rs:58-74): n x n
  * symmetric matrix, zero diagonal, n < 2 -> zeros. Host in, host out. */
@@ -369,6 +386,12 @@ int pn_sharded_query_radius_f64(const pn_sharded *sharded, const double *queries
  * inequality and to measure the matrix core's accumulation error against the allowance the proof makes. */
 int pn_bf16_bounds_f32(const pn_index *index, const float *queries, size_t nq, size_t q_cols,
                        ptrdiff_t q_row_stride, size_t n_rows, float *bounds_out, double *qnorm_out, float *mu_out);
+/* ---- diagnostic: the bf16 tier's hardware self-test (round 4).  The bound allows the matrix core's f32 accumulation an
+ * error of 2^-13 * sum|terms| -- a measured property of gfx950, not a documented one.  The library checks it itself the
+ * first time an index on `device` is given its bf16 tier (synthetic chains of 8 and 65 MFMA steps against terms rebuilt
+ * in f64) and refuses the tier (bf16_eligible = 0, pn_last_error says why) when the error exceeds 2 % of the allowance.
+ * This entry runs the check (again) and returns the measured fraction of the allowance in *ratio_out. */
+int pn_bf16_selftest(int device, float *ratio_out);
 
 /* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
  * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in

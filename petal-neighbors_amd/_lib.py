@@ -20,6 +20,7 @@ PN_OPT_ENGINE, PN_OPT_SEGMENTS, PN_OPT_INDEX_BASE, PN_OPT_PROFILE, PN_OPT_FILTER
 PN_OPT_MFMA_STRUCTURE = 6
 PN_OPT_EXCHANGE_ALWAYS = 7
 PN_OPT_SHARED_THRESHOLDS = 8
+PN_OPT_BF16_WAVES = 9
 
 
 class PnInfo(C.Structure):
@@ -70,6 +71,8 @@ SIGNATURES = {
     "pn_query_nearest_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _vp, _vp]),
     "pn_query_nearest_f64": (_i, [_vp, _vp, _sz, _sz, _ssz, _vp, _vp]),
     "pn_query_radius_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_float, _vp, C.POINTER(_vp)]),
+    "pn_query_radius_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, C.c_float, _vp, _vp, _sz, _vp, _vp]),
+    "pn_query_radius_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, C.c_double, _vp, _vp, _sz, _vp, _vp]),
     "pn_query_radius_f64": (_i, [_vp, _vp, _sz, _sz, _ssz, C.c_double, _vp, C.POINTER(_vp)]),
     "pn_free": (None, [_vp]),
     "pn_pairwise_f32": (_i, [_vp, _sz, _sz, _ssz, _i, _vp]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "pn_merge_topk_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _i, _vp]),
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
     "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp, _vp]),
+    "pn_bf16_selftest": (_i, [_i, _vp]),
     "pn_tree_num_nodes": (_i, [_vp, _u64p]),
     "pn_tree_children_of": (_i, [_vp, _u64, C.POINTER(_i), _u64p, _u64p]),
     "pn_tree_points_of": (_i, [_vp, _u64, C.POINTER(_u64p), _u64p]),

@@ -257,6 +257,31 @@ class BallTree:
         return idx
 
     # --------------------------------------------------------- device-resident
+    def query_radius_device(self, queries, distance, capacity: int, out_offsets=None, out_idx=None, out_total=None,
+                            stream=None):
+        """``query_radius`` with queries and results in HBM, nothing read back (``pn_query_radius_device_*``).
+
+        Returns CUDA tensors ``(offsets int64 [nq+1], idx int64 [capacity], total int64 [1])``: the CSR offsets are always
+        complete; rows are written where their position is below ``capacity``; ``total > capacity`` (whenever the caller
+        looks) means the buffer was too small -- call again with ``capacity >= total``."""
+        import torch
+        tdt = torch.float32 if self._sfx == "f32" else torch.float64
+        if queries.dtype != tdt or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a 2-D CUDA tensor of the tree's element type")
+        if queries.shape[1] > 1 and queries.stride(1) != 1:
+            queries = queries.contiguous()
+        nq, qc = queries.shape
+        dev = queries.device
+        offs = out_offsets if out_offsets is not None else torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        idx = out_idx if out_idx is not None else torch.empty(max(int(capacity), 1), dtype=torch.int64, device=dev)
+        tot = out_total if out_total is not None else torch.empty(1, dtype=torch.int64, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        r = C.c_float(distance) if self._sfx == "f32" else C.c_double(distance)
+        fn = getattr(_lib.lib(), f"pn_query_radius_device_{self._sfx}")
+        check(fn(self._h, queries.data_ptr() if nq * qc else None, nq, qc, queries.stride(0) if nq > 1 else max(qc, 1), r,
+                 offs.data_ptr(), idx.data_ptr(), int(capacity), tot.data_ptr(), C.c_void_p(st)))
+        return offs, idx, tot
+
     def query_device(self, queries, k: int, out_idx=None, out_dist=None, stream=None):
         """k-NN with queries and results in HBM (torch CUDA tensors of the tree's element type; indices as int64)."""
         import torch

@@ -40,6 +40,7 @@ UNITS = [
     ("mfma_filter_v2.hip", []),
     ("bf16_filter.hip", []),
     ("sharded.hip", []),
+    ("radius_device.hip", []),
     ("metric.cpp", ["-ffp-contract=off"]),
     ("tree.cpp", ["-ffp-contract=off"]),
 ]

@@ -328,7 +328,16 @@ template <typename T, bool FILL, bool COS>
 __global__ __launch_bounds__(256) void exact_radius_kernel(
     const T *__restrict__ P, size_t n, int dim, size_t ldp, const T *__restrict__ Q, int nq, size_t ldq, T r,
     size_t seg_len, int nseg, uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
-    uint64_t *__restrict__ fill, uint64_t index_base, const T *__restrict__ pnorm, const T *__restrict__ qnorm) {
+    uint64_t *__restrict__ fill, uint64_t index_base, const T *__restrict__ pnorm, const T *__restrict__ qnorm,
+    const uint32_t *__restrict__ qsel, const uint32_t *__restrict__ nq_dev, uint64_t capacity) {
+    // qsel / nq_dev (nullable; the device-resident entry point, pn_query_radius_device_*): query r of the launch is row
+    // qsel[r] of Q and only the first *nq_dev listed queries exist -- the grid is sized for nq and surplus tiles leave at
+    // once; counts / offsets are indexed by r.  capacity: positions at or beyond it are counted, not written.
+    if (nq_dev) {
+        const uint32_t c = *nq_dev;
+        nq = c < (uint32_t)nq ? (int)c : nq;
+        if ((size_t)blockIdx.x * kTileQ >= (size_t)nq) return;
+    }
     __shared__ __attribute__((aligned(32))) T Qs[kChunkK][kTileQ];
     __shared__ __attribute__((aligned(32))) T Ps[kChunkK][kTileP];
     __shared__ uint32_t cnts[kTileQ];
@@ -343,7 +352,9 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
     if (tid < kTileQ) cnts[tid] = 0;
     __syncthreads();
 
-    const T *Qt = Q + q0 * ldq;
+    const T *Qt = qsel ? Q : Q + q0 * ldq;
+    const uint32_t *qsel_t = qsel ? qsel + q0 : nullptr;
+    const int q_valid = (int)((size_t)nq - q0 < (size_t)kTileQ ? (size_t)nq - q0 : (size_t)kTileQ);
     uint64_t obase[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -353,13 +364,14 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
     bool first = true;
     for (size_t p0 = p_begin; p0 < p_end; p0 += kTileP) {
         T acc[4][4];
-        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb);
+        compute_tile<T, COS>(P + p0 * ldp, ldp, Qt, ldq, dim, first, acc, Qs, Ps, tid, qb, pb, qsel_t, q_valid);
         first = false;
         T qn4[4] = {(T)0, (T)0, (T)0, (T)0}, pn4[4] = {(T)0, (T)0, (T)0, (T)0};
         if (COS) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                qn4[a] = qnorm[q0 + qb + a];
+                const size_t qi = q0 + qb + a;
+                qn4[a] = qsel_t ? (qi < (size_t)nq ? qnorm[qsel_t[qb + a]] : (T)1) : qnorm[qi];
                 pn4[a] = pnorm[p0 + pb + a];
             }
         }
@@ -396,7 +408,10 @@ __global__ __launch_bounds__(256) void exact_radius_kernel(
                 uint64_t pos = obase[a] + before + (inc - c);
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    if (mask[a] & (1u << b)) fill[pos++] = index_base + (uint64_t)(p0 + pb + b);
+                    if (mask[a] & (1u << b)) {
+                        if (pos < capacity) fill[pos] = index_base + (uint64_t)(p0 + pb + b);
+                        ++pos;
+                    }
             }
             wg_fence();
             if (tp == 15) cnts[qb + a] = before + total;
@@ -413,11 +428,12 @@ template <typename T>
 static hipError_t launch_exact_radius(const T *P, size_t n, int dim, size_t ldp, const T *Q, int nq, size_t ldq,
                                       T r, size_t seg_len, int nseg, uint32_t *counts, const uint64_t *offsets,
                                       uint64_t *fill, uint64_t index_base, const T *pnorm, const T *qnorm,
-                                      hipStream_t s) {
+                                      hipStream_t s, const uint32_t *qsel = nullptr, const uint32_t *nq_dev = nullptr,
+                                      uint64_t capacity = ~0ull) {
     dim3 grid((unsigned)(round_up((size_t)nq, kTileQ) / kTileQ), (unsigned)nseg), block(256);
 #define PN_RAD(FF, CC)                                                                                          \
     hipLaunchKernelGGL((exact_radius_kernel<T, FF, CC>), grid, block, 0, s, P, n, dim, ldp, Q, nq, ldq, r, seg_len, \
-                       nseg, counts, offsets, fill, index_base, pnorm, qnorm)
+                       nseg, counts, offsets, fill, index_base, pnorm, qnorm, qsel, nq_dev, capacity)
     if (fill) {
         if (pnorm) PN_RAD(true, true); else PN_RAD(true, false);
     } else {
@@ -429,16 +445,18 @@ static hipError_t launch_exact_radius(const T *P, size_t n, int dim, size_t ldp,
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
                                    const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const float *pnorm,
-                                   const float *qnorm, hipStream_t s) {
+                                   const float *qnorm, hipStream_t s, const uint32_t *qsel, const uint32_t *nq_dev,
+                                   uint64_t capacity) {
     return launch_exact_radius<float>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
-                                      index_base, pnorm, qnorm, s);
+                                      index_base, pnorm, qnorm, s, qsel, nq_dev, capacity);
 }
 hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                    size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
                                    const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const double *pnorm,
-                                   const double *qnorm, hipStream_t s) {
+                                   const double *qnorm, hipStream_t s, const uint32_t *qsel, const uint32_t *nq_dev,
+                                   uint64_t capacity) {
     return launch_exact_radius<double>(P, n, dim, ldp, Q, nq, ldq, r, seg_len, nseg, counts, offsets, fill,
-                                       index_base, pnorm, qnorm, s);
+                                       index_base, pnorm, qnorm, s, qsel, nq_dev, capacity);
 }
 
 // ---------------------------------------------------------------------------

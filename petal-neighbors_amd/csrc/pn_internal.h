@@ -61,6 +61,7 @@ struct CandBuf {
     int cap;         // slots per (segment, query); multiple of 64
     int idx_stride = 1;  // 2: keys and idx interleaved as (key, row) pairs, idx = keys + 1 (bf16 filter)
     int final_keep = 0;  // bf16 filter, 64-slot buffers: a buffer holding at most this many entries ends its run uncut (0: k')
+    int bf16_waves = 0;  // PN_OPT_BF16_WAVES: 0 = the 8-wave main-pass kernel where it applies, 4 = the 4-wave kernel
 };
 
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
@@ -84,11 +85,36 @@ hipError_t launch_exact_knn_f64(const double *P, size_t n, int dim, size_t ldp, 
 hipError_t launch_exact_radius_f32(const float *P, size_t n, int dim, size_t ldp, const float *Q, int nq,
                                    size_t ldq, float r, size_t seg_len, int nseg, uint32_t *counts,
                                    const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const float *pnorm,
-                                   const float *qnorm, hipStream_t s);
+                                   const float *qnorm, hipStream_t s, const uint32_t *qsel = nullptr,
+                                   const uint32_t *nq_dev = nullptr, uint64_t capacity = ~0ull);
 hipError_t launch_exact_radius_f64(const double *P, size_t n, int dim, size_t ldp, const double *Q, int nq,
                                    size_t ldq, double r, size_t seg_len, int nseg, uint32_t *counts,
                                    const uint64_t *offsets, uint64_t *fill, uint64_t index_base, const double *pnorm,
-                                   const double *qnorm, hipStream_t s);
+                                   const double *qnorm, hipStream_t s, const uint32_t *qsel = nullptr,
+                                   const uint32_t *nq_dev = nullptr, uint64_t capacity = ~0ull);
+// qsel / nq_dev (nullable): query r of the launch is row qsel[r] of Q, only the first *nq_dev listed queries exist (grid
+// sized for nq); counts / offsets indexed by r.  capacity: fill positions at or beyond it are not written.
+
+// ---- radius_device.hip: the device-side plumbing of pn_query_radius_device_* (no host round trip)
+// list the queries the exact scan must answer: need[q] = over[q] | bad[q] (either nullable); sel[0 .. *nsel) <- those q
+// ascending, pos[q] <- position in sel or 0xFFFFFFFF; nkept[q] <- 0 for listed queries.  nsel zeroed by the caller.
+hipError_t launch_rad_list(const uint32_t *over, const uint32_t *bad, int nq, uint32_t *nkept, uint32_t *sel,
+                           uint32_t *pos, uint32_t *nsel, hipStream_t s);
+// per-query result counts: fin[q] = pos[q] valid ? sum_seg counts_x[pos[q] * nseg + seg] : nkept[q]
+// (pos / nkept nullable: every query listed at its own position / none kept)
+hipError_t launch_rad_counts(const uint32_t *nkept, const uint32_t *pos, const uint32_t *counts_x, int nseg, int nq,
+                             uint32_t *fin, hipStream_t s);
+// offsets[0 .. n] <- exclusive prefix sums of in[0 .. n) (64-bit); scratch: >= (n / 4096 + 2) * 8 bytes; total (nullable)
+// <- offsets[n]
+hipError_t launch_exclusive_scan_u32(const uint32_t *in, size_t n, uint64_t *offsets, uint64_t *scratch, uint64_t *total,
+                                     hipStream_t s);
+// offs_x[r * nseg + seg] <- offsets[sel ? sel[r] : r] + sum_{t < seg} counts_x[r * nseg + t], r < (nsel ? *nsel : nq)
+hipError_t launch_rad_seg_offsets(const uint64_t *offsets, const uint32_t *sel, const uint32_t *nsel, int nq,
+                                  const uint32_t *counts_x, int nseg, uint64_t *offs_x, hipStream_t s);
+// out[offsets[q] + e] <- index_base + kept[q * kept_stride + e], e < nkept[q], positions below capacity only
+hipError_t launch_radius_gather_cap(const uint32_t *kept, const uint32_t *nkept, const uint64_t *offsets, int nq,
+                                    size_t kept_stride, uint64_t index_base, uint64_t *out, uint64_t capacity,
+                                    hipStream_t s);
 // Cosine's norms: norms[i] = sqrt(sequential sum of x_i[k]^2, k < dim) in T
 hipError_t launch_cosine_norms_f32(const float *X, size_t n, int dim, size_t ld, float *norms, hipStream_t s);
 hipError_t launch_cosine_norms_f64(const double *X, size_t n, int dim, size_t ld, double *norms, hipStream_t s);
@@ -253,6 +279,9 @@ int bf16_query_tile();                             // queries per workgroup (256
 // (zeroed by the caller)
 template <typename T>  // T = float | double (explicitly instantiated): the index's element type
 hipError_t launch_bf16_column_sums(const T *P, size_t n, int dim, size_t ld, double *sums, hipStream_t s);
+// out[0] <- the largest |delivered - exact| / (2^-13 sum|terms|) over synthetic chains of 8 and 65 MFMA steps: the matrix
+// core's accumulation error against the allowance the bf16 bound makes for it (bf16_filter.hip, bf16_selftest_kernel)
+hipError_t launch_bf16_selftest(float *out, hipStream_t s);
 // mu [dim] <- the per-dimension mean (f32) when translating by it shrinks the sum of squared norms 16x (wide rows: 2x), else
 // zero; words[0] <- 1 / 0 accordingly.  never: always zero (diagnostic builds)
 hipError_t launch_bf16_decide_mu(const double *sums, size_t n, int dim, bool never, float *mu, uint32_t *words, hipStream_t s);

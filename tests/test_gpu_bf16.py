@@ -427,3 +427,20 @@ def test_radius_reruns_of_a_few_dense_queries_on_a_larger_corpus(pn, oracle_mod)
         assert np.array_equal(idx[int(off[a]):int(off[a + 1])], want), a
     st = tree.stats()
     assert 1 <= st["fallback_queries"] <= 4, st
+
+
+def test_library_checks_the_matrix_cores_accumulation_itself(pn):
+    """the proof's allowance g = 2^-13 for the matrix core's f32 accumulation is a measured property
+    of gfx950; the guard used to be the two pytest measurements above.  Now the library contracts synthetic chains (8 and
+    65 MFMA steps, mixed signs and scales, non-zero accumulator) the first time an index on a device gets its bf16 tier,
+    compares with the terms rebuilt in f64, and refuses the tier above 2 % of the allowance.  pn_bf16_selftest reruns
+    that check and reports the fraction."""
+    from petal_neighbors_amd import _lib
+    from petal_neighbors_amd.errors import check
+    r = C.c_float(-1.0)
+    check(_lib.lib().pn_bf16_selftest(0, C.byref(r)))
+    print(f"matrix-core accumulation self-test: {r.value:.5f} of the allowance")
+    assert 0.0 <= r.value < 0.02, r.value            # measured by the pytest twins: <= 0.0016
+    assert r.value > 0.0                              # it did contract something (f32 accumulation is not exact)
+    tree = pn.BallTree.euclidean(uniform((4096, 64), 77))
+    assert tree.bf16_eligible                         # and the verdict let the tier through
