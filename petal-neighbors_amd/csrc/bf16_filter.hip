@@ -3250,7 +3250,7 @@ constexpr bool kBf8Enabled = false;
 constexpr bool kBf8Enabled = true;
 #endif
 #ifndef PN_BF8_MAXRUN
-#define PN_BF8_MAXRUN 250
+#define PN_BF8_MAXRUN 450
 #endif
 constexpr uint32_t kBf8MaxRun = PN_BF8_MAXRUN;  // runs shorter than this many tiles take the 8-wave main-pass kernel
 template <int KS, int M, bool RAD, bool CI>
@@ -3288,9 +3288,12 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         // Measured on one device (round 4, profiles/r04_waves_ab.log): at C2 (1302-tile runs) the 8-wave kernel is 7-9 %
         // SLOWER than the 4-wave kernel (2.47-2.50 vs 2.28-2.31 ms: twice the LDS fragment traffic, an 8-wave meeting per
         // tile), on a 125 k-row shard of C2 (163-tile runs, where the per-run fixed costs and the buffers' warm-up
-        // dominate) 3-5 % faster -- so it serves the short runs (kBf8MaxRun tiles), and PN_OPT_BF16_WAVES forces either.
+        // dominate) 3-5 % faster -- so it serves the short runs (kBf8MaxRun tiles) and the 128-slot buffers, and
+        // PN_OPT_BF16_WAVES forces either.
         const uint32_t run_tiles = aligned ? n_tiles / ((uint32_t)n_wg / q_tiles) : 0u;
-        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && run_tiles < kBf8MaxRun);
+        // (second box: a 250 k-row shard, 326-tile runs, 2.5 % faster; a 500 k-row shard, 651 tiles, 3 % slower; 128-slot
+        // buffers -- k = 100, survivors frequent -- 2 % faster at 1M x 128 and 10 % at 1M x 64 whatever the run length)
+        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && (M == 2 || run_tiles < kBf8MaxRun));
         if (want8 && aligned && !scout_out && (tau_init || bsh.seed_lists) && kBf8Enabled) {
             if (use_sh && (!tau_init || shp->n_refresh < 1)) return hipErrorInvalidValue;
             BfShared a = bsh;

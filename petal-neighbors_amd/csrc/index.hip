@@ -655,12 +655,28 @@ extern "C" int pn_index_create_device_f64(const double *d_points, size_t n_rows,
     return create_from_device<double>(d_points, n_rows, n_cols, row_stride, device, stream, out);
 }
 
+// Everything this handle has enqueued -- on its own streams or on callers' (the *_device entry points) -- has finished:
+// every call holds a workspace for its duration and leaves an end-of-use event on the stream it ran on (ws_release), so
+// waiting for the workspaces' events is waiting for the handle, and for nothing else on the device (round 3 called
+// hipDeviceSynchronize here: a device-wide wait behind a per-handle call).  `all`: also workspaces that are leased right
+// now (pn_index_destroy: no call may be in progress); else only released ones (a concurrent call is simply not waited for).
+static void handle_wait(const pn_index *ix, bool all) {
+    std::vector<hipEvent_t> evs;
+    {
+        std::lock_guard<std::mutex> lk(ix->sh.mu);
+        for (Workspace *ws : (all ? ix->sh.all_ws : ix->sh.free_ws))
+            if (ws->in_flight && ws->done) evs.push_back(ws->done);
+    }
+    for (hipEvent_t e : evs) (void)hipEventSynchronize(e);
+}
+
 extern "C" void pn_index_destroy(pn_index *ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
     // queries may have been enqueued on caller streams (the *_device entry points): nothing of this
     // index may be freed while any of them is still running
-    (void)hipDeviceSynchronize();
+    handle_wait(ix, true);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     for (Workspace *ws : ix->sh.all_ws) {
         for (DevBuf *b : ws->all) b->release();
         ws->free_retired();
@@ -916,7 +932,7 @@ extern "C" int pn_index_get_stats(const pn_index *ix, pn_stats *out, int reset) 
     if (!ix || !out) return fail(PN_ERR_INVALID, "NULL argument");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(PN_ERR_DEVICE, "hipSetDevice(%d) failed", ix->device);
-    HIPCHK(hipDeviceSynchronize());
+    handle_wait(ix, false);  // this handle's calls, not the device (see handle_wait)
     std::lock_guard<std::mutex> lk(ix->sh.mu);
     recs_collect(ix, true);
     unsigned long long h[kPnStatWords] = {0};  // [0] fallback queries, then kPnStatSlots pairs {candidates, evaluations}
@@ -2728,7 +2744,7 @@ static int pairwise_impl(const T *x, size_t n, size_t cols, ptrdiff_t row_stride
         else if (e == hipSuccess)
             e = (sizeof(T) == 4) ? launch_exact_pairwise_f32((const float *)d_p, n, (int)cols, ld, (float *)d_o, nullptr)
                                  : launch_exact_pairwise_f64((const double *)d_p, n, (int)cols, ld, (double *)d_o, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (the kernels above ran on the default stream)
         if (e == hipSuccess) e = hipMemcpy(out, d_o, n * n * sizeof(T), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(PN_ERR_DEVICE, "pairwise: %s", hipGetErrorString(e));
     } while (0);

@@ -252,6 +252,10 @@ template <> struct ShT<float> {
                      uint64_t *oi, float *od, int dev, void *s, bool signed_keys) {
         return merge_topk_device_keys_f32(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s, signed_keys);
     }
+    static int radius_device(const pn_index *ix, const float *q, size_t nq, size_t qc, size_t qs, float r, uint64_t *off,
+                             uint64_t *idx, size_t cap, uint64_t *tot, void *st) {
+        return pn_query_radius_device_f32(ix, q, nq, qc, qs, r, off, idx, cap, tot, st);
+    }
     static int radius(const pn_index *ix, const float *q, size_t nq, size_t qc, ptrdiff_t qs, float r, uint64_t *off,
                       uint64_t **out) {
         return pn_query_radius_f32(ix, q, nq, qc, qs, r, off, out);
@@ -271,6 +275,10 @@ template <> struct ShT<double> {
     static int merge(const uint64_t *pi, const double *pd, size_t np, size_t is, size_t ds, size_t nq, size_t kp, size_t ko,
                      uint64_t *oi, double *od, int dev, void *s, bool signed_keys) {
         return merge_topk_device_keys_f64(pi, pd, np, is, ds, nq, kp, ko, oi, od, dev, s, signed_keys);
+    }
+    static int radius_device(const pn_index *ix, const double *q, size_t nq, size_t qc, size_t qs, double r, uint64_t *off,
+                             uint64_t *idx, size_t cap, uint64_t *tot, void *st) {
+        return pn_query_radius_device_f64(ix, q, nq, qc, qs, r, off, idx, cap, tot, st);
     }
     static int radius(const pn_index *ix, const double *q, size_t nq, size_t qc, ptrdiff_t qs, double r, uint64_t *off,
                       uint64_t **out) {
@@ -293,7 +301,11 @@ extern "C" int pn_comm_unique_id(void *id_out) {
 
 static void destroy_dev(Dev &d) {
     SetGuard g(d.device);
-    (void)hipDeviceSynchronize();
+    // what this handle enqueued on d -- on its own streams or a caller's -- has finished: the end-of-use event of the last
+    // call (DevUse) and the handle's own streams; not a device-wide wait
+    if (d.in_flight && d.ev_use) (void)hipEventSynchronize(d.ev_use);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
     if (d.comm && rccl().ok()) (void)rccl().CommDestroy(d.comm);
     Buf *bufs[] = {&d.q, &d.out_idx, &d.out_dist, &d.lparts, &d.pack[0], &d.pack[1], &d.gathered[0], &d.gathered[1],
                    &d.rad_a, &d.rad_b};
@@ -827,6 +839,73 @@ static int sharded_query_radius(const pn_sharded *sh, const T *queries, size_t n
     if (nq == 0) return PN_OK;
     if (!queries && q_cols) return set_error(PN_ERR_INVALID, "queries is NULL");
     std::lock_guard<std::mutex> lk(sh->mu);
+    if (sh->rank_mode && (sh->world > 1 || sh->exchange_always)) {
+        // One process per GPU (round 4): the local shard answers through the DEVICE entry point (pn_query_radius_device_*:
+        // counts, scan and fill in HBM), its CSR offsets are all-gathered as they lie in HBM, and the lists travel device
+        // to device -- the host sees the gathered offsets once (to size the exchange) and the gathered lists once (to
+        // splice).  Round 3 built a host CSR on every rank first (two stream synchronisations inside pn_query_radius_*)
+        // and uploaded counts and lists again.
+        Dev &d = sh->devs[0];
+        SetGuard g(d.device);
+        if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
+        SPN(acquire_dev(d, d.stream));
+        const size_t W = (size_t)sh->world, qc = q_cols ? q_cols : 1;
+        const pn_index *lix = sh->parts.empty() ? nullptr : sh->parts[0].ix;
+        if (q_row_stride < 0) return set_error(PN_ERR_UNSUPPORTED, "negative row stride");
+        SPN(d.q.ensure(nq * qc * sizeof(T)));
+        if (q_cols) {
+            if (nq == 1 || (size_t)q_row_stride == q_cols)
+                SHIP(hipMemcpyAsync(d.q.p, queries, nq * q_cols * sizeof(T), hipMemcpyHostToDevice, d.stream));
+            else
+                SHIP(hipMemcpy2DAsync(d.q.p, q_cols * sizeof(T), queries, (size_t)q_row_stride * sizeof(T),
+                                      q_cols * sizeof(T), nq, hipMemcpyHostToDevice, d.stream));
+        }
+        // rad_a: [local offsets nq + 1 | total 1 | pad 1 | gathered offsets W (nq + 1)]
+        const size_t no = nq + 1;
+        SPN(d.rad_a.ensure((no + 2 + W * no) * 8));
+        uint64_t *d_off = (uint64_t *)d.rad_a.p, *d_tot = d_off + no, *d_all = d_off + no + 2;
+        size_t cap = d.rad_b.bytes / 8 / (W + 1);      // this rank's share of what rad_b holds already
+        if (cap < nq * 4 + 1024) cap = nq * 4 + 1024;
+        std::vector<uint64_t> all_off(W * no);
+        uint64_t longest = 1;
+        for (int attempt = 0;; ++attempt) {
+            SPN(d.rad_b.ensure((cap + W * cap) * 8));
+            uint64_t *d_mine = (uint64_t *)d.rad_b.p;
+            if (lix)
+                SPN(ShT<T>::radius_device(lix, (const T *)d.q.p, nq, q_cols, qc, radius, d_off, d_mine, cap, d_tot, d.stream));
+            else
+                SHIP(hipMemsetAsync(d_off, 0, (no + 1) * 8, d.stream));  // a rank without rows: every list empty
+            SNCCL(rccl().AllGather(d_off, d_all, no, ncclUint64, d.comm, d.stream));
+            SHIP(hipMemcpyAsync(all_off.data(), d_all, W * no * 8, hipMemcpyDeviceToHost, d.stream));
+            SHIP(hipStreamSynchronize(d.stream));
+            longest = 1;
+            for (size_t r = 0; r < W; ++r) longest = std::max<uint64_t>(longest, all_off[r * no + nq]);
+            if (longest <= cap) break;  // every rank's list fits its buffer (all ranks see the same numbers: same decision)
+            if (attempt) return set_error(PN_ERR_DEVICE, "radius lists changed size between two passes");
+            cap = (size_t)longest;      // some rank overflowed: everybody re-runs with room for the longest list
+        }
+        uint64_t *d_mine = (uint64_t *)d.rad_b.p, *d_lists = d_mine + cap;
+        SNCCL(rccl().AllGather(d_mine, d_lists, (size_t)longest, ncclUint64, d.comm, d.stream));
+        std::vector<uint64_t> all_ids((size_t)(W * longest));
+        SHIP(hipMemcpyAsync(all_ids.data(), d_lists, (size_t)(W * longest) * 8, hipMemcpyDeviceToHost, d.stream));
+        SHIP(hipStreamSynchronize(d.stream));
+        uint64_t total = 0;
+        for (size_t r = 0; r < W; ++r) total += all_off[r * no + nq];
+        uint64_t *res = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+        if (!res) return set_error(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)total);
+        uint64_t w = 0;
+        for (size_t a = 0; a < nq; ++a) {  // per query, the ranks' (ascending) lists in rank order: shards are ascending row ranges
+            offsets[a] = w;
+            for (size_t r = 0; r < W; ++r) {
+                const uint64_t lo = all_off[r * no + a], c = all_off[r * no + a + 1] - lo;
+                if (c) memcpy(res + w, all_ids.data() + r * longest + lo, (size_t)c * sizeof(uint64_t));
+                w += c;
+            }
+        }
+        offsets[nq] = w;
+        *idx_out = res;
+        return PN_OK;
+    }
     const size_t np = sh->parts.size();
     std::vector<std::vector<uint64_t>> offs(np, std::vector<uint64_t>(nq + 1, 0));
     std::vector<uint64_t *> lists(np, nullptr);
@@ -855,7 +934,7 @@ static int sharded_query_radius(const pn_sharded *sh, const T *queries, size_t n
                 w += c;
             }
     }
-    if (!sh->rank_mode || sh->world == 1) {
+    {
         uint64_t *res = (uint64_t *)malloc((l_total ? l_total : 1) * sizeof(uint64_t));
         if (!res) return set_error(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)l_total);
         if (l_total) memcpy(res, l_ids.data(), (size_t)l_total * sizeof(uint64_t));
@@ -868,49 +947,6 @@ static int sharded_query_radius(const pn_sharded *sh, const T *queries, size_t n
         *idx_out = res;
         return PN_OK;
     }
-    // one process per GPU: counts, then padded lists, by all-gather
-    Dev &d = sh->devs[0];
-    SetGuard g(d.device);
-    if (!g.ok) return set_error(PN_ERR_DEVICE, "hipSetDevice(%d) failed", d.device);
-    const size_t W = (size_t)sh->world;
-    SPN(d.rad_a.ensure((nq + W * nq) * 8));
-    uint64_t *d_cnt = (uint64_t *)d.rad_a.p, *d_all = d_cnt + nq;
-    SHIP(hipMemcpyAsync(d_cnt, l_cnt.data(), nq * 8, hipMemcpyHostToDevice, d.stream));
-    SNCCL(rccl().AllGather(d_cnt, d_all, nq, ncclUint64, d.comm, d.stream));
-    std::vector<uint64_t> all_cnt(W * nq);
-    SHIP(hipMemcpyAsync(all_cnt.data(), d_all, W * nq * 8, hipMemcpyDeviceToHost, d.stream));
-    SHIP(hipStreamSynchronize(d.stream));
-    std::vector<uint64_t> tot(W, 0);
-    uint64_t longest = 1;
-    for (size_t r = 0; r < W; ++r) {
-        for (size_t a = 0; a < nq; ++a) tot[r] += all_cnt[r * nq + a];
-        longest = std::max(longest, tot[r]);
-    }
-    SPN(d.rad_b.ensure((size_t)(longest + W * longest) * 8));
-    uint64_t *d_mine = (uint64_t *)d.rad_b.p, *d_lists = d_mine + longest;
-    if (l_total) SHIP(hipMemcpyAsync(d_mine, l_ids.data(), (size_t)l_total * 8, hipMemcpyHostToDevice, d.stream));
-    SNCCL(rccl().AllGather(d_mine, d_lists, (size_t)longest, ncclUint64, d.comm, d.stream));
-    std::vector<uint64_t> all_ids((size_t)(W * longest));
-    SHIP(hipMemcpyAsync(all_ids.data(), d_lists, (size_t)(W * longest) * 8, hipMemcpyDeviceToHost, d.stream));
-    SHIP(hipStreamSynchronize(d.stream));
-    uint64_t total = 0;
-    for (size_t r = 0; r < W; ++r) total += tot[r];
-    uint64_t *res = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
-    if (!res) return set_error(PN_ERR_NOMEM, "malloc(%llu results) failed", (unsigned long long)total);
-    std::vector<uint64_t> pos(W, 0);
-    uint64_t w = 0;
-    for (size_t a = 0; a < nq; ++a) {
-        offsets[a] = w;
-        for (size_t r = 0; r < W; ++r) {
-            const uint64_t c = all_cnt[r * nq + a];
-            if (c) memcpy(res + w, all_ids.data() + r * longest + pos[r], (size_t)c * sizeof(uint64_t));
-            pos[r] += c;
-            w += c;
-        }
-    }
-    offsets[nq] = w;
-    *idx_out = res;
-    return PN_OK;
 }
 extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
                                            ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out) {

@@ -271,7 +271,17 @@ class HipShardEngine:
         return buf
 
     def radius(self, queries, r: float):
-        return self.tree.query_radius_batch(queries.cpu().numpy(), r)
+        """the shard's CSR through the device entry point (pn_query_radius_device_*: counts, scan and fill in HBM); the
+        host looks at the total once, to size the copy -- and calls again with room for it when the buffer was short"""
+        nq = queries.shape[0]
+        cap = max(4 * nq, 1024)
+        while True:
+            offs, idx, tot = self.tree.query_radius_device(queries, r, cap)
+            total = int(tot.item())
+            if total <= cap:
+                break
+            cap = total
+        return offs.cpu().numpy().astype(np.uint64), idx[:total].cpu().numpy().astype(np.uint64)
 
     def merge(self, idx_parts, dist_parts, k_out: int):
         """parts: (G, nq, k_part) CUDA tensors (any part stride, rows contiguous) -> (nq, k_out)."""
