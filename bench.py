@@ -259,6 +259,23 @@ def committed_traffic(kernel_name, config_key):
     return traffic, src
 
 
+def committed_kernel_split(config_key):
+    """Mean durations of the dominant kernel's two launches of a step (scout-only launch, main launch) from the committed
+    rocprofv3 --kernel-trace --stats record of this same command (profiles/*kernel_split*.json, written by
+    tools/kernel_split.py from the stats CSV): the library brackets both launches with ONE pair of hipEvents (every event
+    record costs the stream ~6 us), so the live number is their sum, kernel_ms_per_step."""
+    try:
+        import glob
+        best = None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernel_split*.json"))):
+            d = json.load(open(f))
+            if d.get("config") == config_key:
+                best = (d, os.path.relpath(f, ROOT))
+        return best
+    except Exception:
+        return None
+
+
 def bench_f64(args):
     """--dtype f64: the same k-NN step on an f64 index (the reference is generic over A and its own harness is f64,
     benches/ball_tree.rs:9-13): the bf16 MFMA filter over the f64 corpus' tile images, then the f64 re-rank, proof and
@@ -362,9 +379,9 @@ def bench_f64(args):
                      **({"traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})"}
                         if traffic_src else {}),
                      "kernel": kernel_name,
-                     "mfma_dtype": "bf16" if bf else "none (f64 vector unit)", "kernel_ms": round(hot_ms, 4),
-                     "flops_per_launch": flops_per_launch, "launches_per_step": round(launches / max(args.steps, 1), 2),
-                     "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4)},
+                     "mfma_dtype": "bf16" if bf else "none (f64 vector unit)",
+                     "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4),
+                     "flops_per_step": 2.0 * n * dim * nq, "launches_per_step": round(launches / max(args.steps, 1), 2)},
         "verified": bool(verified["ok"]) if verified else None, "verify": verified,
         "fallback_queries": int(st["fallback_queries"]),
         "candidates_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
@@ -634,9 +651,34 @@ def main():
     st = tree.stats() if tree is not None else {"hot_launches": 0, "hot_ms": 0.0, "fallback_queries": 0, "candidates": 0,
                                                  "queries": 0, "evaluations": 0}
 
+    radius_device = None
+    if args.mode == "radius":
+        # the same queries through pn_query_radius_device_* (queries and CSR in HBM, counts scanned on the device, nothing
+        # read back inside the timed region), side by side with the host API's number above
+        total = int(out[0][-1])
+        cap = total + total // 8 + 1024
+        d_off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        d_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+        d_tot = torch.empty(1, dtype=torch.int64, device=dev)
+        for _ in range(max(args.warmup, 1)):
+            tree.query_radius_device(queries, radius, cap, d_off, d_ids, d_tot)
+        torch.cuda.synchronize()
+        t0d = time.perf_counter()
+        for _ in range(args.steps):
+            tree.query_radius_device(queries, radius, cap, d_off, d_ids, d_tot)
+        torch.cuda.synchronize()
+        el_d = time.perf_counter() - t0d
+        same = (int(d_tot.item()) == total and np.array_equal(d_off.cpu().numpy().astype(np.uint64), out[0]) and
+                np.array_equal(d_ids[:total].cpu().numpy().astype(np.uint64), out[1]))
+        radius_device = {"entry": "pn_query_radius_device_f32 (queries and CSR resident in HBM, no host round trip)",
+                         "ms_per_step": round(el_d / args.steps * 1e3, 4), "value": round(nq * args.steps / el_d, 1),
+                         "unit": "queries/s", "capacity": cap, "equals_host_api": bool(same)}
     verified = None
     if not args.no_verify and args.mode == "radius":
         verified = verify_radius(out, q_host, n, dim, nq, radius, tree)
+        if radius_device is not None and not radius_device["equals_host_api"]:
+            verified["ok"] = False
+            verified["checks"].append("device API == host API: FAILED")
     elif not args.no_verify:
         verified = verify(out, queries, n, dim, nq, k, rank, world, index, gen)
         if dist:
@@ -670,6 +712,12 @@ def main():
         # this kernel and config on one GPU, else null.
         traffic, traffic_src = (None, None) if world != 1 else \
             committed_traffic(kernel_name, args.config + ("_radius" if args.mode == "radius" else ""))
+        traffic_ms = None
+        if traffic_src:
+            try:
+                traffic_ms = json.load(open(os.path.join(ROOT, traffic_src))).get("kernel_ms_mean_under_pmc")
+            except Exception:
+                traffic_ms = None
         if args.mode == "radius":
             kernel_name = "bf16_wide_kernel" if dim > 128 else "bf16_filter_kernel"
         line = {
@@ -694,14 +742,23 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "kernel": kernel_name, "mfma_dtype": "bf16" if engine_used == "bf16" else "f32",
-                         "kernel_ms": round(hot_ms, 4), "flops_per_launch": flops_per_launch,
-                         "launches_per_step": round(launches / max(args.steps, 1), 2),
+                         # live: ONE hipEvent bracket per step around the kernel's launches (scout-only + main for the
+                         # bf16 tier); achieved = the step's algorithmic flops / that time
                          "kernel_ms_per_step": round(st["hot_ms"] / max(args.steps, 1), 4),
+                         "flops_per_step": 2.0 * n_local * dim * nq,
+                         "launches_per_step": round(launches / max(args.steps, 1), 2),
+                         **(lambda ks: ({"kernel_ms_main": ks[0]["main_ms"], "kernel_ms_scout": ks[0]["scout_ms"],
+                                         "kernel_split_source": f"{ks[1]} (rocprofv3 --kernel-trace --stats of this command; "
+                                                                f"main + scout = {ks[0]['main_ms'] + ks[0]['scout_ms']:.4f} ms)"}
+                                        if ks else {}))(committed_kernel_split(args.config) if world == 1 and args.mode == "knn" else None),
+                         **({"traffic_kernel_ms_under_pmc": traffic_ms} if traffic_ms else {}),
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
                                                   / (peak * world), 4)},
             "verified": bool(verified["ok"]) if verified else None,
             "verify": verified,
-            **({"radius": radius, "results_per_query": round(float(out[0][-1]) / nq, 4)} if args.mode == "radius" else {}),
+            **({"radius": radius, "results_per_query": round(float(out[0][-1]) / nq, 4),
+                "host_api": {"ms_per_step": round(ms_per_step, 4), "value": round(qps, 1), "unit": "queries/s"},
+                "device_api": radius_device} if args.mode == "radius" else {}),
             # N > 1 (or a forced exchange): the step's local half (this rank's filter + re-rank over its shard) and its
             # exchange half (ncclAllGather + merge), hipEvents on the call's stream inside the library, rank 0's
             **({"shard_ms": round(st["shard_ms"] / max(args.steps, 1), 4),

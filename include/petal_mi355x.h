@@ -377,6 +377,14 @@ int pn_sharded_query_device_f64(const pn_sharded *sharded, const double *d_queri
                                 size_t q_row_stride, size_t k, uint64_t *d_idx_out, double *d_dist_out, void *stream);
 int pn_sharded_query_radius_f64(const pn_sharded *sharded, const double *queries, size_t nq, size_t q_cols,
                                 ptrdiff_t q_row_stride, double radius, uint64_t *offsets, uint64_t **idx_out);
+/* pn_query_radius_device_* on a sharded handle with ONE shard (what a rank of a one-GPU job holds); several shards:
+ * PN_ERR_UNSUPPORTED -- their ragged exchange goes through the host entry point above. */
+int pn_sharded_query_radius_device_f32(const pn_sharded *sharded, const float *d_queries, size_t nq, size_t q_cols,
+                                       size_t q_row_stride, float radius, uint64_t *d_offsets, uint64_t *d_idx,
+                                       size_t capacity, uint64_t *d_total, void *stream);
+int pn_sharded_query_radius_device_f64(const pn_sharded *sharded, const double *d_queries, size_t nq, size_t q_cols,
+                                       size_t q_row_stride, double radius, uint64_t *d_offsets, uint64_t *d_idx,
+                                       size_t capacity, uint64_t *d_total, void *stream);
 
 /* ---- diagnostic: the first-tier filter's lower bounds themselves.  bounds_out[q * n_rows + i] = L'(q, p_i)
  * for the first n_rows corpus rows (clamped to n_points), with L' + qnorm_out[q] <= |q - p_i|^2 in real

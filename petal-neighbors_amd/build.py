@@ -46,7 +46,7 @@ UNITS = [
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(CSRC, "topk_buffer.h"),
+HEADERS = [os.path.join(CSRC, "pn_internal.h"), os.path.join(CSRC, "topk_buffer.h"), os.path.join(CSRC, "host_tree.h"),
            os.path.join(os.path.dirname(HERE), "include", "petal_mi355x.h")]
 
 

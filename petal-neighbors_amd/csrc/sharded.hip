@@ -948,6 +948,28 @@ static int sharded_query_radius(const pn_sharded *sh, const T *queries, size_t n
         return PN_OK;
     }
 }
+// query_radius with queries and CSR in HBM (pn_query_radius_device_*): a handle with ONE shard forwards to it (global row
+// numbers through the shard's index base).  Several shards would need the ragged exchange on the device as well: the
+// host entry point above serves them.
+template <typename T>
+static int sharded_query_radius_device(const pn_sharded *sh, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, T radius,
+                                       uint64_t *d_offsets, uint64_t *d_idx, size_t capacity, uint64_t *d_total, void *stream) {
+    if (!sh) return set_error(PN_ERR_INVALID, "handle is NULL");
+    SPN(check_elem(sh, sizeof(T)));
+    if (sh->n_shards != 1 || sh->parts.size() != 1 || !sh->parts[0].ix)
+        return set_error(PN_ERR_UNSUPPORTED, "the device-resident query_radius serves handles with one shard");
+    return ShT<T>::radius_device(sh->parts[0].ix, d_q, nq, q_cols, q_stride, radius, d_offsets, d_idx, capacity, d_total, stream);
+}
+extern "C" int pn_sharded_query_radius_device_f32(const pn_sharded *sh, const float *d_q, size_t nq, size_t q_cols,
+                                                  size_t q_stride, float radius, uint64_t *d_offsets, uint64_t *d_idx,
+                                                  size_t capacity, uint64_t *d_total, void *stream) {
+    return sharded_query_radius_device<float>(sh, d_q, nq, q_cols, q_stride, radius, d_offsets, d_idx, capacity, d_total, stream);
+}
+extern "C" int pn_sharded_query_radius_device_f64(const pn_sharded *sh, const double *d_q, size_t nq, size_t q_cols,
+                                                  size_t q_stride, double radius, uint64_t *d_offsets, uint64_t *d_idx,
+                                                  size_t capacity, uint64_t *d_total, void *stream) {
+    return sharded_query_radius_device<double>(sh, d_q, nq, q_cols, q_stride, radius, d_offsets, d_idx, capacity, d_total, stream);
+}
 extern "C" int pn_sharded_query_radius_f32(const pn_sharded *sh, const float *queries, size_t nq, size_t q_cols,
                                            ptrdiff_t q_row_stride, float radius, uint64_t *offsets, uint64_t **idx_out) {
     return sharded_query_radius<float>(sh, queries, nq, q_cols, q_row_stride, radius, offsets, idx_out);

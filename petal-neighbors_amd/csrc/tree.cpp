@@ -18,7 +18,7 @@
 #include <new>
 #include <vector>
 
-#include "pn_internal.h"
+#include "host_tree.h"
 
 namespace pn {
 

@@ -186,6 +186,29 @@ class ShardedIndex:
                 out_idx.data_ptr(), out_dist.data_ptr(), C.c_void_p(st)))
         return out_idx, out_dist
 
+    def query_radius_device(self, queries, distance, capacity: int, out_offsets=None, out_idx=None, out_total=None,
+                            stream=None):
+        """``pn_sharded_query_radius_device_*`` (one-shard handles): see ``BallTree.query_radius_device``."""
+        import torch
+        from . import _lib
+        from .errors import check
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        if queries.dtype != tdt or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a 2-D CUDA tensor of the handle's dtype (%s)" % self.dtype)
+        if queries.shape[1] > 1 and queries.stride(1) != 1:
+            queries = queries.contiguous()
+        nq, qc = queries.shape
+        dev = queries.device
+        offs = out_offsets if out_offsets is not None else torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        idx = out_idx if out_idx is not None else torch.empty(max(int(capacity), 1), dtype=torch.int64, device=dev)
+        tot = out_total if out_total is not None else torch.empty(1, dtype=torch.int64, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        r = C.c_double(distance) if self.dtype == np.float64 else C.c_float(distance)
+        fn = getattr(_lib.lib(), f"pn_sharded_query_radius_device_{self._sfx}")
+        check(fn(self._h, queries.data_ptr() if nq * qc else None, nq, qc, queries.stride(0) if nq > 1 else max(qc, 1), r,
+                 offs.data_ptr(), idx.data_ptr(), int(capacity), tot.data_ptr(), C.c_void_p(st)))
+        return offs, idx, tot
+
     def query_radius_batch(self, queries, distance):
         """CSR (offsets[nq+1], indices) of ``{ i : dist(q, p_i) < distance }`` over all shards, ascending per query."""
         from . import _lib

@@ -6,5 +6,5 @@ timeout -k 10 300 PN_LIBRARY_PATH=$GRAFT_REPO_ROOT/petal-neighbors_amd/libpetal_
 python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/abl_$3.json').read().strip().splitlines()[-1]); r=d['roofline']
-print('$3', 'kern', r['kernel_ms'], 'ms', d['ms_per_step'], 'fb', d['fallback_queries'], 'cand', d['candidates_per_query'])
+print('$3', 'kern', r['kernel_ms_per_step'], 'ms', d['ms_per_step'], 'fb', d['fallback_queries'], 'cand', d['candidates_per_query'])
 "
