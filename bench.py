@@ -62,6 +62,8 @@ CONFIGS = {
     "c5m": (1_000_000, 96, 200_000, 10),         # many queries: one workgroup per query tile
     "c3m": (1_000_000, 128, 200_000, 100),
     "c3k10": (10_000_000, 128, 100_000, 10),     # configs[2]'s corpus and batch at k = 10 (grid in rounds, short buffers)
+    "c2k500": (1_000_000, 128, 10_000, 500),     # large k at the headline shape (the tier's limits)
+    "c2k1000": (1_000_000, 128, 10_000, 1000),
     "d64": (1_000_000, 64, 10_000, 10),          # narrower rows (kernel experiments)
     "d64k100": (1_000_000, 64, 10_000, 100),
 }

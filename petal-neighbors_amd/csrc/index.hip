@@ -198,7 +198,7 @@ struct pn_index {
     void *d_pts = nullptr;   // [n_pad][ld], zero padded
     float *d_norm = nullptr; // f32 only: scaled squared norms for the MFMA lower bound
     bool mfma_ok = false;
-    void *d_img = nullptr;   // f32, D <= 1024: bf16 tile images of the corpus (bf16_filter.hip)
+    void *d_img = nullptr;   // D <= 4096: bf16 tile images of the corpus (bf16_filter.hip)
     float *d_mu = nullptr;   // translation vector of the bf16 tier: the corpus mean per dimension, or zero
     bool centered = false;   // d_mu != 0: translating shrinks the squared norms at least 16x
     bool bf16_ok = false;
@@ -894,7 +894,7 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             if (ix->metric == 1 && value == PN_ENGINE_MFMA)
                 return fail(PN_ERR_UNSUPPORTED, "a Cosine index is served by the bf16 filter or the exact scan");
             if (value == PN_ENGINE_BF16 && !ix->bf16_ok)
-                return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (f64, D > 1024, fewer than 64 rows or out-of-range values)");
+                return fail(PN_ERR_UNSUPPORTED, "the bf16 filter cannot serve this index (D > 4096, fewer than 64 rows or out-of-range values)");
             if (value == PN_ENGINE_MFMA && !ix->mfma_ok)
                 return fail(PN_ERR_UNSUPPORTED, "the MFMA filter cannot serve this index (f64, non-finite norms or unsupported shape)");
             ix->engine = (int)value;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["uniform", "centered", "offset1000", "mixed_scales", "sparse", "scaled1e6"])
-@pytest.mark.parametrize("dim", [129, 200, 768, 1024])
+@pytest.mark.parametrize("dim", [129, 200, 768, 1024, 1536, 4096])
 def test_wide_lower_bound_inequality(pn, name, dim):
     n, nq = 1024, 64
     pts = CASES[name](n, dim, 31)
@@ -32,9 +32,9 @@ def test_wide_lower_bound_inequality(pn, name, dim):
 
 
 @pytest.mark.parametrize("name", ["centered", "offset1000", "mixed_scales", "uniform"])
-@pytest.mark.parametrize("dim", [256, 768, 1024])
+@pytest.mark.parametrize("dim", [256, 768, 1024, 2048, 4096])
 def test_wide_accumulation_error_is_far_inside_the_allowance(pn, name, dim):
-    """chains of up to 65 MFMA steps (D = 1024): |delivered - exact sum of the bf16 x bf16 terms| <= g sum|terms|"""
+    """chains of up to 257 MFMA steps (D = 4096; round 3: 65 at D = 1024): |delivered - exact sum of the bf16 x bf16 terms| <= g sum|terms|"""
     from test_bf16_bound_model import corpus_columns, query_columns, G
     n, nq = 512, 64
     pts = CASES[name](n, dim, 41)
@@ -52,7 +52,8 @@ def test_wide_accumulation_error_is_far_inside_the_allowance(pn, name, dim):
 
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 256, 300, 10), (9000, 768, 257, 10), (6000, 1024, 64, 5),
                                           (12000, 200, 700, 1), (5000, 129, 1, 3), (30000, 384, 100, 100),
-                                          (4097, 144, 513, 7), (300, 512, 40, 4)])
+                                          (4097, 144, 513, 7), (300, 512, 40, 4), (6000, 1536, 130, 10),
+                                          (3000, 3072, 40, 5), (2000, 4096, 20, 3), (5000, 1030, 33, 3)])
 def test_wide_engine_parity(pn, oracle_mod, n, dim, nq, k):
     pts = uniform((n, dim), 300 + dim)
     qs = uniform((nq, dim), 400 + dim)
@@ -104,11 +105,13 @@ def test_wide_nonfinite_queries(pn, oracle_mod):
     assert np.array_equal(idx[ok], oidx[ok])
 
 
-def test_rows_beyond_1024_columns_have_no_bf16_tier(pn, oracle_mod):
-    pts = uniform((5000, 1030), 81)
+def test_rows_beyond_4096_columns_have_no_bf16_tier(pn, oracle_mod):
+    """(round 4: the tier's limit went from 1024 to 4096 columns -- 257 MFMA steps, a chain length the library's own
+    self-test contracts; beyond it the f32 tiers answer)"""
+    pts = uniform((1500, 4100), 81)
     tree = pn.BallTree.euclidean(pts)
     assert not tree.bf16_eligible
-    qs = uniform((33, 1030), 82)
+    qs = uniform((33, 4100), 82)
     idx, dist = tree.query_batch(qs, 3)
     oidx, odist = oracle_mod.brute_knn(pts, qs, 3)
     assert dist.tobytes() == odist.tobytes() and np.array_equal(idx, oidx)
