@@ -1406,10 +1406,34 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     const double n_sigma = ix->n < ((size_t)4 << 20) ? (ci_many ? 4.0 : 5.0) : (ci_many ? 5.0 : 5.5);
     size_t per_tile = n_wg / q_tiles;  // workgroups (= segments) per query tile
     if (per_tile < 1) per_tile = 1;
+    // Large k (round 4).  A query's R relevant rows spread over its per_tile segments, a buffer holds at most 224
+    // candidates (k' + 32 <= 256 slots), and k' = R / per_tile + margin: at 1M x 128 the 12 segments of the headline plan
+    // serve k up to ~370.  Beyond that MORE, SHORTER segments per query tile -- a grid of c workgroups per query tile run
+    // in rounds, as for many query tiles -- keep k' inside a buffer: k = 500 stays at 12 segments (k' = 143), k = 1000
+    // takes 24 (two rounds of 480 workgroups).  Round 3 "split the rows into parts" here, which does not add
+    // workgroups: with n_wg >= q_tiles * split a query still has per_tile segments, k' was planned for twice as many,
+    // and 97 % of a k = 500 batch failed its proof -- after which the index switched the tier off (126 ms per batch
+    // on the exact engine; 853 ms at k = 1000).
+    if (level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0 && n_wg >= q_tiles) {
+        auto kp_of = [&](size_t c) {
+            const double per = R / (double)c;
+            return per + n_sigma * std::sqrt(per) + 3.0;
+        };
+        size_t c = per_tile;
+        while (kp_of(c) > 200.0 && c + per_tile <= 96 && r_tiles / (c + per_tile) >= 32) c += per_tile;
+        if (c != per_tile && kp_of(c) <= 224.0) {
+            per_tile = c;
+            n_wg = q_tiles * c;
+            p.n_wg = (int)n_wg;
+        }
+    }
     auto kp_for = [&](int split) -> double {
         if (ix->filter_slots > 0) return (double)((size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots);
         if (level != 0) return R + 6.0 * std::sqrt(R) + 4.0;
-        const double per = R / (double)(per_tile * (size_t)split);
+        // segments a query's rows are spread over: its workgroups, or its row parts when a workgroup walks several
+        // (parts do not multiply the workgroups of a query tile: see above)
+        const size_t segs = per_tile > (size_t)split ? per_tile : (size_t)split;
+        const double per = R / (double)segs;
         const double v = per + n_sigma * std::sqrt(per) + 3.0;  // ~1e-6 per (query, segment) of holding more than that
         return v < 8.0 ? 8.0 : v;
     };
@@ -1417,7 +1441,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // (every part pays its own warm-up), and keep parts of at least 256 tiles
     p.split = 1;
     if (level == 0 && ix->opt_segments == 0 && ix->filter_slots == 0)
-        while (p.split < 8 && kp_for(p.split) > 96.0 && r_tiles / (size_t)(2 * p.split) >= 256) p.split *= 2;
+        while (p.split < 8 && kp_for(p.split) > 96.0 && r_tiles / (size_t)(2 * p.split) >= 256 &&
+               (size_t)(2 * p.split) > per_tile)  // (only where more parts ARE more segments: few workgroups per query tile)
+            p.split *= 2;
     double kp = kp_for(p.split);
     // A k' between 17 and 31 lives in 128-slot buffers anyway, so the tail it is planned against costs nothing but
     // candidates there: the count of relevant rows varies from query to query (22 +- 5.3, up to 44 of 256 queries for
@@ -1425,7 +1451,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // 10M x 128, 10^5 queries, k = 10, 5 segments: k' = 20 left 15 queries per batch to the second tier -- 15 exact
     // scans of 10^7 rows, 22 of the step's 215 ms; planned for twice the mean (k' = 30): see DESIGN.md 4.0.
     if (level == 0 && ix->filter_slots == 0 && kp > 16.0 && kp < 32.0) {
-        const double per2 = 2.0 * R / (double)(per_tile * (size_t)p.split);
+        const double per2 = 2.0 * R / (double)(per_tile > (size_t)p.split ? per_tile : (size_t)p.split);
         const double v = per2 + n_sigma * std::sqrt(per2) + 3.0;
         kp = v < 32.0 ? (v > kp ? v : kp) : 32.0;
     }

@@ -12,5 +12,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc/p$i -o p -- python3 $R/bench.py --no-verify --no-cpu-baseline --steps 2 --warmup 1 $BA > $O/pmc_p$i.log 2>&1 || { echo pmc pass $i failed; tail -3 $O/pmc_p$i.log; exit 1; }
   echo "pass $i done"
 done
-python3 $R/tools/pmc_summary.py $KN $O/pmc > $O/pmc_summary.json
+python3 $R/tools/pmc_summary.py "$KN" $O/pmc > $O/pmc_summary.json
 cat $O/pmc_summary.json

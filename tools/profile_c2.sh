@@ -15,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc/p$i -o p -- python3 $R/bench.py --no-verify --no-cpu-baseline --steps 3 --warmup 1 $BA > $O/pmc_p$i.log 2>&1 || { echo pmc pass $i failed; tail -3 $O/pmc_p$i.log; exit 1; }
 done
-python3 $R/tools/pmc_summary.py $KN $O/pmc > $O/pmc_summary.json
+python3 $R/tools/pmc_summary.py "$KN" $O/pmc > $O/pmc_summary.json
 cat $O/pmc_summary.json
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 head -8 $O/kernel_stats.csv
