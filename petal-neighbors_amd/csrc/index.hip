@@ -1218,7 +1218,7 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // feed NaN or negative numbers into plan geometry.  0 = not set.
 struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
-    size_t sh_min_run = 0;
+    size_t sh_min_run = 0, wide_per_tile = 0;
     bool debug = false;
 };
 static const PlanKnobs &plan_knobs() {
@@ -1234,6 +1234,7 @@ static const PlanKnobs &plan_knobs() {
         v.scout_lambda = num("PN_EXP_SCOUT_LAMBDA", 0.01, 64.0);
         v.scout_cap = num("PN_EXP_SCOUT_CAP", 1.0, 64.0);
         v.sh_min_run = (size_t)num("PN_EXP_SH_MIN_RUN", 1.0, 1.0e6);
+        v.wide_per_tile = (size_t)num("PN_EXP_WIDE_PER_TILE", 1.0, 32.0);
         v.debug = getenv("PN_DEBUG_PLAN") != nullptr;
         return v;
     }();
@@ -1280,6 +1281,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
     }
     size_t best = 1;
     while (best < c_max && eff_of(best) < best_eff - 0.08) ++best;
+    if (plan_knobs().wide_per_tile && plan_knobs().wide_per_tile <= c_max) best = plan_knobs().wide_per_tile;  // experiments only
     const double R = (ix->centered ? 1.5 : 2.0) * (double)kout + 4.0;
     double segs = 2.0;
     for (;; best = (best + 1) / 2) {
