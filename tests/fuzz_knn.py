@@ -15,11 +15,13 @@ from conftest import uniform  # noqa: E402
 
 def run_case(c, rng):
     n = int(rng.choice([64, 1000, 3000, 4096, 5000, 9000, 20000, 33000, 60000]))  # (<= 4096 with few queries: one-launch path)
-    dim = int(rng.choice([3, 8, 15, 16, 31, 64, 96, 100, 128, 129, 200, 384, 768, 1024]))
+    dim = int(rng.choice([3, 8, 15, 16, 31, 64, 96, 100, 128, 129, 200, 384, 768, 1024, 1536, 2048]))
     nq = int(rng.choice([1, 7, 64, 255, 256, 257, 600, 1300]))
     if dim > 128:  # wide rows (K-chunked bf16 kernel): keep the oracle's brute force to seconds
         n, nq = min(n, 20000), min(nq, 600)
-    k = int(rng.choice([1, 2, 5, 10, 33, 100]))
+    k = int(rng.choice([1, 2, 5, 10, 33, 100, 100, 300, 700]))  # (round 4: large k through more segments per query tile)
+    if k > 100 and (dim > 128 or n < 3000):
+        k = 100
     kind = rng.choice(["uniform", "centered", "clustered", "dups", "sorted"])
     f64 = bool(rng.integers(0, 3) == 0)  # a third of the cases: an f64 index (bf16 filter, f64 re-rank and second tier)
     pts = uniform((n, dim), 1000 + c)
@@ -39,10 +41,33 @@ def run_case(c, rng):
         if kind == "dups":
             pts[n // 2:] = pts[: n - n // 2]
         qs = qs.astype(np.float64) + uniform((nq, dim), 32000 + c).astype(np.float64) * 2.0 ** -26
+    from petal_neighbors_amd import _lib
     t = pn.BallTree.euclidean(pts)
+    waves = int(rng.choice([0, 4, 8]))  # (round 4: either main-pass kernel of the bf16 tier)
+    t.set_option(_lib.PN_OPT_BF16_WAVES, waves)
     idx, dist = t.query_batch(qs, k)
     oi, od = oracle.brute_knn(pts, qs, k)
     ok = dist.tobytes() == od.tobytes() and np.array_equal(idx, oi)
+    # round 4: the same corpus as a Cosine index -- the bf16 tier over the normalised rows against the exact scan of the same
+    # index (bit for bit, NaN distances aside) and, where it is cheap, the oracle's pairwise(x, &Cosine)
+    if c % 3 == 0 and n <= 33000:
+        try:
+            tc = pn.BallTree.new(pts, pn.distance.Cosine())
+            kc = min(k, 100)
+            ci, cd = tc.query_batch(qs, kc)
+            tc.set_engine("exact")
+            ei, ed = tc.query_batch(qs, kc)
+            nan = np.isnan(ed)
+            ok = ok and np.array_equal(np.isnan(cd), nan) and cd[~nan].tobytes() == ed[~nan].tobytes() and np.array_equal(ci[~nan], ei[~nan])
+            if n <= 5000 and nq <= 64:
+                dm = oracle.pairwise_cosine(np.vstack([qs, pts]))[:nq, nq:]
+                for a in range(nq):
+                    nn_ = np.isnan(dm[a])
+                    order = np.lexsort((np.arange(n), np.where(nn_, np.inf, dm[a]), nn_))[:kc]
+                    fin = ~np.isnan(dm[a][order])
+                    ok = ok and np.array_equal(ci[a][fin], order[fin].astype(np.uint64)) and cd[a][fin].tobytes() == dm[a][order][fin].tobytes()
+        except pn.PetalError:
+            ok = False
     # radius queries through the same tiers: a radius just above / exactly at a stored distance (strict '<')
     nr = min(nq, 8)
     ft = np.float64 if f64 else np.float32
@@ -52,6 +77,16 @@ def run_case(c, rng):
         off, ids = t.query_radius_batch(qs[:nr], float(r))
         for a in range(nr):
             ok = ok and np.array_equal(ids[int(off[a]):int(off[a + 1])], oracle.brute_radius(pts, qs[a], r))
+        # round 4: the device entry point (counts, scan and fill in HBM), with room for everything and with a short buffer
+        import torch
+        qd = torch.from_numpy(np.ascontiguousarray(qs[:nr])).to("cuda:0")
+        total = int(off[-1])
+        for cap in (total + 5, max(total // 2, 1)):
+            do, di, dt = t.query_radius_device(qd, float(r), cap)
+            torch.cuda.synchronize()
+            m = min(cap, total)
+            ok = ok and int(dt.item()) == total and np.array_equal(do.cpu().numpy().astype(np.uint64), off) and \
+                np.array_equal(di.cpu().numpy().astype(np.uint64)[:m], ids[:m])
     st = t.stats()
     print(f"case {c}: n={n} D={dim} nq={nq} k={k} {kind}{' f64' if f64 else ''}: {'ok' if ok else 'MISMATCH'} fallback {st['fallback_queries']}/{st['queries']} cand/q {st['candidates']/max(st['queries'],1):.0f}", flush=True)
     return ok
