@@ -3285,7 +3285,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
     }
     // The 8-wave kernel (bf16_filter8_kernel): main pass of a k-NN call (thresholds given), 64-slot buffers, aligned
     // partition -- every workgroup one whole run
-    if constexpr (M <= 2 && !RAD && !kBfCapture) {
+    if constexpr (M <= 4 && !RAD && !kBfCapture) {
         const bool aligned = split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0;
         // Measured on one device (round 4, profiles/r04_waves_ab.log): at C2 (1302-tile runs) the 8-wave kernel is 7-9 %
         // SLOWER than the 4-wave kernel (2.47-2.50 vs 2.28-2.31 ms: twice the LDS fragment traffic, an 8-wave meeting per
@@ -3295,9 +3295,9 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         const uint32_t run_tiles = aligned ? n_tiles / ((uint32_t)n_wg / q_tiles) : 0u;
         // (second box: a 250 k-row shard, 326-tile runs, 2.5 % faster; a 500 k-row shard, 651 tiles, 3 % slower; 128-slot
         // buffers -- k = 100, survivors frequent -- 2 % faster at 1M x 128 and 10 % at 1M x 64 whatever the run length)
-        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && (M == 2 || run_tiles < kBf8MaxRun));
+        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && (M >= 2 || run_tiles < kBf8MaxRun));
         if (want8 && aligned && !scout_out && (tau_init || bsh.seed_lists) && kBf8Enabled) {
-            if (use_sh && (!tau_init || shp->n_refresh < 1)) return hipErrorInvalidValue;
+            if (use_sh && (!tau_init || shp->n_refresh < 1 || M > 2)) return hipErrorInvalidValue;
             BfShared a = bsh;
             if (use_sh) {
                 a.pcnt = shp->pcnt;
