@@ -2982,7 +2982,8 @@ extern "C" int pn_debug_read_bf(unsigned long long *out, int reset) {
 // kernel contracts synthetic operands of mixed signs and scales over chains of 8, 65 and 257 steps from a non-zero
 // accumulator (the narrow kernel's chain, the wide kernel's at D = 1024 and at its limit D = 4096), rebuilds every term in f64 -- bf16 x bf16
 // products are exact there, and 1041 of them sum with a relative error below 2^-42 -- and reports the largest
-// |delivered - exact| / (g * sum|terms|).  The host refuses the tier above 0.02 (what the tests assert).  One wave.
+// |delivered - exact| / (g * sum|terms|).  The host refuses the tier above 0.02 (what the tests assert).  One wave,
+// ~0.5 ms, once per process and device (rocprofv3, round 4: 1.2 ms with twice the checked outputs).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint16_t bf_selftest_val(uint32_t i, uint32_t k, uint32_t salt) {
     uint32_t x = (i * 0x9E3779B1u) ^ (k * 0x85EBCA77u) ^ (salt * 0xC2B2AE3Du);
@@ -2993,8 +2994,8 @@ __device__ __forceinline__ uint16_t bf_selftest_val(uint32_t i, uint32_t k, uint
 __global__ __launch_bounds__(64) void bf16_selftest_kernel(float *__restrict__ out) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     float worst = 0.0f;
-    constexpr int NR = 4;                       // registers checked per lane (256 of the 1024 outputs of a block)
-    const int regs[NR] = {0, 5, 10, 15};
+    constexpr int NR = 2;                       // registers checked per lane (128 of the 1024 outputs of a block; the f64
+    const int regs[NR] = {3, 12};               // reference, not the MFMAs, is this kernel's time: ~0.5 ms once per device)
     for (int pass = 0; pass < 3; ++pass) {
         const int steps = pass == 0 ? 8 : pass == 1 ? 65 : 257;
         f32x16 acc;
