@@ -142,6 +142,11 @@ __device__ __forceinline__ float f_up(double x) {  // smallest float >= x (x >= 
     if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
     return f;
 }
+__device__ __forceinline__ float f_up_signed(double x) {  // smallest float >= x, any sign (finite x)
+    float f = (float)x;
+    if ((double)f < x) f = (f >= 0.0f) ? __uint_as_float(__float_as_uint(f) + 1u) : __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
 __device__ __forceinline__ uint16_t bf_trunc(float x) { return (uint16_t)(__float_as_uint(x) >> 16); }  // x >= 0
 __device__ __forceinline__ uint16_t bf_up(float x) {  // x >= 0: smallest bf16 >= x
     const uint32_t u = __float_as_uint(x);
@@ -675,7 +680,7 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
                                           size_t nq_pad, int dim, size_t ld, int KS, uint16_t *__restrict__ B,
                                           double *__restrict__ qn, uint32_t *__restrict__ qbad, int ci, double bmax,
                                           double dmax, T *__restrict__ Qp, size_t ldq,
-                                          uint32_t *__restrict__ misc) {
+                                          uint32_t *__restrict__ misc, Bf16SeedModel sm) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t q = t >> 3;
     const int sub = (int)(t & 7);
@@ -684,7 +689,7 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
     const int K = 16 * KS, CH = 2 * KS, E = bf16_extra_col(dim);
     const int c0 = sub * CH;
     uint16_t v[18];  // CH <= 18 (KS <= 9)
-    double s = 0.0, en = 0.0, hn = 0.0;
+    double s = 0.0, en = 0.0, hn = 0.0, sm_mean = 0.0, sm_var = 0.0;
     bool finite = true;
     const T *src = Q + q * ld;
     if (Qp) {  // columns of the padded copy that no lane's eighth of the K columns covers (ldq > K, e.g. D = 100)
@@ -743,6 +748,10 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
             const double e = c - (double)xh;
             en += e * e;
             hn += (double)xh * (double)xh;
+            if (sm.seed_out) {  // seed model: this coordinate's share of the bound's mean and variance over the corpus
+                sm_mean += c * (double)sm.m1[k];
+                sm_var += c * (c * (double)sm.a[k] - (double)sm.b[k]);
+            }
         }
     }
     uint32_t fin = finite ? 1u : 0u;
@@ -752,6 +761,13 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
         en += __shfl_xor(en, d);
         hn += __shfl_xor(hn, d);
         fin &= (uint32_t)__shfl_xor((int)fin, d);
+    }
+    if (sm.seed_out) {
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            sm_mean += __shfl_xor(sm_mean, d);
+            sm_var += __shfl_xor(sm_var, d);
+        }
     }
     const bool ok = fin != 0u && (s < 1.2676506002282294e30);
     if (!ok) {
@@ -782,6 +798,22 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
             qn[q] = ok ? s / kUp : 0.0;
         }
         qbad[q] = ok ? 0u : 1u;
+        if (sm.seed_out) {
+            // Starting threshold from the index's seed model (Bf16SeedModel): over the corpus rows p the bound
+            // L'(q, p) ~ sum_k (u_k^2 - 2 a_k u_k), u = p - t, a = q - t, has mean c0 - 2 sum a_k M1_k and variance
+            // v0 + sum (A_k a_k^2 - B_k a_k) (coordinates taken as independent; z is CALIBRATED against the scout's
+            // own seeds on corpus rows at index build, so what the model gets wrong on average is inside z).  ANY
+            // threshold is valid: a seed that is too low only sends the query to the next tier (and switches the
+            // model off), one that is too high costs appends.  Padding queries and bad ones: -inf (nothing passes).
+            float sd = __uint_as_float(0xFF800000u);
+            if (q < nq && ok) {
+                const double var = sm.v0 + sm_var;
+                const double S = sm.c0 - 2.0 * sm_mean - sm.z * sqrt(var > 0.0 ? var : 0.0);
+                sd = f_up_signed(S);
+            }
+            const uint32_t key = f2s(sd);
+            sm.seed_out[q] = (sd == sd && key != 0xFFFFFFFFu && q < nq && ok) ? key + 1u : f2s(__uint_as_float(0xFF800000u));
+        }
     }
 }
 
@@ -2925,10 +2957,14 @@ __global__ __launch_bounds__(512, 1) void bf16_wide_kernel(const char *__restric
                 m1 = fminf(m1, acc[rb][1][i]);
             }
             const uint32_t row0 = rt * (uint32_t)kWR + (uint32_t)(rh * 128 + rb * 32);
+#ifdef PN_DIAG_BF_WIDE_NOSLOW  // TIMING / TRAFFIC ONLY (wrong results): no survivor handling -- co-walking workgroups do not drift
+            asm volatile("" ::"v"(m0), "v"(m1), "v"(row0));
+#else
             if (__any(m0 < tau0))
                 bf_slow<M, RAD>(acc[rb][0], m0, tau0, cnt0, row0, h, jq, lane, kp, ceq0, ce_blk0, ns BF_DBG_PASS);
             if (__any(m1 < tau1))
                 bf_slow<M, RAD>(acc[rb][1], m1, tau1, cnt1, row0, h, jq, lane, kp, ceq1, ce_blk1, ns BF_DBG_PASS);
+#endif
         }
     }
     // ---- end of run: at most kp candidates per query stay; publish count and threshold
@@ -3211,16 +3247,20 @@ bool bf16_pack_fused_supported(int dim) {
 template <typename T>
 hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s, T *Qp, size_t ldq, uint32_t *misc) {
+                                    hipStream_t s, T *Qp, size_t ldq, uint32_t *misc, const Bf16SeedModel *smp) {
     if ((Qp || misc) && !bf16_pack_fused_supported(dim)) return hipErrorInvalidValue;
+    Bf16SeedModel sm{};
+    if (smp) sm = *smp;
+    if (sm.seed_out && (bf16_is_wide(dim) || !sm.m1 || !sm.a || !sm.b)) return hipErrorInvalidValue;
 #ifndef PN_DIAG_BF_PACKQ1
     if (!bf16_is_wide(dim)) {  // nq_pad is a multiple of 256: whole blocks
         hipLaunchKernelGGL(bf16_pack_queries8_kernel<T>, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
                            nq_pad, dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, ci ? 1 : 0,
-                           bmax, dmax, Qp, ldq, misc);
+                           bmax, dmax, Qp, ldq, misc, sm);
         return hipGetLastError();
     }
 #endif
+    if (sm.seed_out) return hipErrorInvalidValue;  // (model seeds come from the eight-lanes-per-query kernel only)
 #ifndef PN_DIAG_BF_PACK1
     if (bf16_is_wide(dim) && !ci && nq_pad % 32 == 0) {  // (nq_pad is a multiple of 256 for wide rows)
         hipLaunchKernelGGL((bf16_pack_wide8_kernel<T, true>), dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq, nq_pad,
@@ -3233,10 +3273,45 @@ hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size
                        ci ? 1 : 0, bmax, dmax);
     return hipGetLastError();
 }
+// Per-dimension power sums of the corpus translated by mu: out[j * dim + k] = sum over rows of (p_k - mu_k)^(j + 1),
+// j = 0 .. 3, in f64 (the seed model's moments; zeroed by the caller).  Non-finite coordinates count as zero.
+template <typename T>
+__global__ void bf16_column_moments_kernel(const T *__restrict__ P, const float *__restrict__ mu, size_t n, int dim, size_t ld,
+                                           double *__restrict__ out) {
+    const size_t r0 = (size_t)blockIdx.x * 1024;
+    const size_t r1 = r0 + 1024 < n ? r0 + 1024 : n;
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
+        const double m = (double)mu[k];
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+        for (size_t r = r0; r < r1; ++r) {
+            const double x = (double)P[r * ld + k];
+            const double u = (fabs(x) < 1.0e30) ? x - m : 0.0;
+            const double u2 = u * u;
+            s1 += u;
+            s2 += u2;
+            s3 += u2 * u;
+            s4 += u2 * u2;
+        }
+        atomicAdd(&out[k], s1);
+        atomicAdd(&out[dim + k], s2);
+        atomicAdd(&out[2 * dim + k], s3);
+        atomicAdd(&out[3 * dim + k], s4);
+    }
+}
+template <typename T>
+hipError_t launch_bf16_column_moments(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_column_moments_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(128), 0, s, P, mu, n, dim, ld, out);
+    return hipGetLastError();
+}
+template hipError_t launch_bf16_column_moments<float>(const float *, const float *, size_t, int, size_t, double *, hipStream_t);
+template hipError_t launch_bf16_column_moments<double>(const double *, const float *, size_t, int, size_t, double *, hipStream_t);
+
 template hipError_t launch_bf16_pack_queries<float>(const float *, const float *, size_t, size_t, int, size_t, void *, double *,
-                                                    uint32_t *, bool, double, double, hipStream_t, float *, size_t, uint32_t *);
+                                                    uint32_t *, bool, double, double, hipStream_t, float *, size_t, uint32_t *,
+                                                    const Bf16SeedModel *);
 template hipError_t launch_bf16_pack_queries<double>(const double *, const float *, size_t, size_t, int, size_t, void *, double *,
-                                                     uint32_t *, bool, double, double, hipStream_t, double *, size_t, uint32_t *);
+                                                     uint32_t *, bool, double, double, hipStream_t, double *, size_t, uint32_t *,
+                                                     const Bf16SeedModel *);
 
 // The branch-free capture path (CAPT, see the kernel) is measured, parity-tested and NOT used by default: it wins where
 // survivors are frequent and the kernel is launched with thresholds (1M x 128, k = 100: 4.50 -> 4.20 ms) but needs ~25
@@ -3286,7 +3361,7 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
     }
     // The 8-wave kernel (bf16_filter8_kernel): main pass of a k-NN call (thresholds given), 64-slot buffers, aligned
     // partition -- every workgroup one whole run
-    if constexpr (M <= 4 && !RAD && !kBfCapture) {
+    if constexpr (M <= 4 && !RAD && !kBfCapture && kBf8Enabled) {
         const bool aligned = split == 1 && (uint32_t)n_wg >= q_tiles && (uint32_t)n_wg % q_tiles == 0;
         // Measured on one device (round 4, profiles/r04_waves_ab.log): at C2 (1302-tile runs) the 8-wave kernel is 7-9 %
         // SLOWER than the 4-wave kernel (2.47-2.50 vs 2.28-2.31 ms: twice the LDS fragment traffic, an 8-wave meeting per

@@ -301,10 +301,23 @@ hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int di
 // kernel also writes the zero-padded f32 copy Qp[nq_pad][ldq] and zeroes the 16 counter words at misc -- the three
 // launches at the head of a call in one
 bool bf16_pack_fused_supported(int dim);
+// Seed model of an index (round 4; index.hip, seed_model_build): starting thresholds of a k-NN call from per-dimension
+// moments of the corpus instead of a scout launch.  m1 / a / b: [dim] f32 (M1_k, 4 (M2_k - M1_k^2), 4 (M3_k - M2_k M1_k)
+// of u = p - mu), c0 = sum M2_k, v0 = sum (M4_k - M2_k^2), z = the calibrated number of standard deviations below the mean;
+// seed_out [nq_pad] receives the sortable keys (nullptr: no seeds).
+struct Bf16SeedModel {
+    const float *m1 = nullptr, *a = nullptr, *b = nullptr;
+    double c0 = 0.0, v0 = 0.0, z = 0.0;
+    uint32_t *seed_out = nullptr;
+};
 template <typename T>
 hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size_t nq_pad, int dim, size_t ld,
                                     void *B, double *qn, uint32_t *qbad, bool ci, double bmax, double dmax,
-                                    hipStream_t s, T *Qp = nullptr, size_t ldq = 0, uint32_t *misc = nullptr);
+                                    hipStream_t s, T *Qp = nullptr, size_t ldq = 0, uint32_t *misc = nullptr,
+                                    const Bf16SeedModel *sm = nullptr);
+// out[j * dim + k] += sum over rows of (p_k - mu_k)^(j + 1), j = 0 .. 3 (zeroed by the caller)
+template <typename T>
+hipError_t launch_bf16_column_moments(const T *P, const float *mu, size_t n, int dim, size_t ld, double *out, hipStream_t s);
 // split: row parts per query tile (>= 1); cb.nseg >= bf16_segments(q_tiles, n_wg, split); scout_max: cap on the
 // tiles of a run that are contracted first, without buffers, to seed the threshold (0 = no scouting)
 int bf16_segments(size_t q_tiles, int n_wg, int split);
