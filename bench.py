@@ -304,6 +304,10 @@ def bench_f64(args):
     tree = pn.BallTree.new(pts, pn.distance.Cosine()) if cosine else pn.BallTree.euclidean(pts)
     tree.set_engine(args.engine)
     tree.set_option(_lib.PN_OPT_PROFILE, 1)
+    if args.seed_model >= 0:
+        tree.set_option(_lib.PN_OPT_SEED_MODEL, args.seed_model)
+    if args.waves:
+        tree.set_option(_lib.PN_OPT_BF16_WAVES, args.waves)
     qd = torch.from_numpy(qs).to("cuda:0")
     out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device="cuda:0")
     out_dst = torch.empty((nq, min(k, n)), dtype=torch.float64 if f64 else torch.float32, device="cuda:0")
@@ -508,6 +512,9 @@ def main():
                     help="PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto (library default), >= 2 the rank itself")
     ap.add_argument("--waves", type=int, default=0, choices=[0, 4, 8],
                     help="PN_OPT_BF16_WAVES: 0 = library default (by run length), 4 / 8 = force that main-pass kernel")
+    ap.add_argument("--seed-model", type=int, default=-1, choices=[-1, 0, 1],
+                    help="PN_OPT_SEED_MODEL: 0 = always scout, 1 = thresholds from the index's seed model where accepted "
+                         "(library default)")
     ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
                     help="abi: the all-gather is RCCL behind the C ABI (pn_sharded_*); torch: torch.distributed")
     args = ap.parse_args()
@@ -605,6 +612,8 @@ def main():
             tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, args.shared_thresholds)
         if args.waves:
             tree.set_option(_lib.PN_OPT_BF16_WAVES, args.waves)
+        if args.seed_model >= 0:
+            tree.set_option(_lib.PN_OPT_SEED_MODEL, args.seed_model)
         tree.set_option(_lib.PN_OPT_PROFILE, 1)
     n_local = index.n_local
     out_idx = torch.empty((nq, min(k, n)), dtype=torch.int64, device=dev)

@@ -94,11 +94,15 @@ enum {
                                   workgroups in the idle workgroup slots); 0 = off; n >= 2 = on with the shared
                                   threshold at the n-th smallest bound of the union (experiments).  Never changes a
                                   result: only how many candidates the filter keeps. */
-    PN_OPT_BF16_WAVES = 9        /* bf16 tier, narrow rows, main pass of a k-NN call: 0 (default) = the library picks -- the
+    PN_OPT_BF16_WAVES = 9,       /* bf16 tier, narrow rows, main pass of a k-NN call: 0 (default) = the library picks -- the
                                   8-wave kernel (one 32-query column block per wave, four waves per SIMD) for short runs,
                                   the 4-wave kernel (two column blocks per wave, two waves per SIMD) for long ones; 4 / 8
                                   = always that kernel where it applies.  Never changes a result (A/B measurements,
                                   tests of both kernels). */
+    PN_OPT_SEED_MODEL = 10       /* bf16 tier, indexes of narrow rows (D <= 128) whose seed model was accepted at build
+                                  (pn_info.seed_model): 1 (default) = k-NN calls with k <= 128 take their starting
+                                  thresholds from the model (no scout launch); 0 = always scout.  Never changes a result:
+                                  a threshold only decides which tier answers a query. */
 };
 
 typedef struct pn_index pn_index;
@@ -113,7 +117,8 @@ typedef struct pn_info {
     int32_t bf16_eligible; /* 1 when the bf16 MFMA filter path can serve this index */
     int32_t bf16_layout;   /* 0 none; 1 = five extra columns per row; 2 = row norm as the accumulator's initial value and
                               a per-query error constant (rows of homogeneous norm, D mod 16 in {0, 12..15}) */
-    int32_t reserved;
+    int32_t seed_model;    /* 1 when the index's seed model was accepted at build: uniform-like
+                              corpora; clustered ones keep the scout launch */
 } pn_info;
 
 typedef struct pn_stats {

@@ -21,12 +21,13 @@ PN_OPT_MFMA_STRUCTURE = 6
 PN_OPT_EXCHANGE_ALWAYS = 7
 PN_OPT_SHARED_THRESHOLDS = 8
 PN_OPT_BF16_WAVES = 9
+PN_OPT_SEED_MODEL = 10
 
 
 class PnInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("dim", C.c_uint64), ("row_stride_device", C.c_uint64),
                 ("elem_bytes", C.c_int32), ("device", C.c_int32), ("mfma_eligible", C.c_int32),
-                ("bf16_eligible", C.c_int32), ("bf16_layout", C.c_int32), ("reserved", C.c_int32)]
+                ("bf16_eligible", C.c_int32), ("bf16_layout", C.c_int32), ("seed_model", C.c_int32)]
 
 
 class PnStats(C.Structure):

@@ -47,6 +47,7 @@ class BallTree:
         self.mfma_eligible = bool(info.mfma_eligible)
         self.bf16_eligible = bool(info.bf16_eligible)
         self.bf16_layout = int(info.bf16_layout)
+        self.seed_model = bool(info.seed_model)
 
     # ------------------------------------------------------------ construction
     @classmethod

@@ -187,6 +187,7 @@ struct CallRec {
     size_t nq = 0;
     uint64_t call_id = 0;
     bool pending = false, busy = false, two_launches = false, has_flag = false, bf16_tier = false, hot = false;
+    bool model_seed = false;  // the call's thresholds came from the index's seed model (no scout launch)
     int prof = 0;  // PN_OPT_PROFILE at rec_begin: 1 = the dominant kernel's brackets, 2 = also the whole chunk's
 };
 constexpr int kCallRecs = 16;
@@ -219,6 +220,12 @@ struct pn_index {
     int mfma_structure = 0;  // 0 auto, 1 = grid of (query tile x segment), 2 = persistent balanced partition
     int shared_tau = 1;      // PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto, >= 2 the rank itself
     int bf16_waves = 0;      // PN_OPT_BF16_WAVES: 0 auto (8-wave main-pass kernel where it applies), 4 = 4-wave kernel
+    // Seed model (round 4, seed_model_build): starting thresholds of a k-NN call from per-dimension moments of the corpus,
+    // calibrated against the scout's own seeds at build time -- the calls it serves run WITHOUT the scout launch.
+    float *d_smodel = nullptr;   // [3][ld] f32: M1_k | 4 (M2_k - M1_k^2) | 4 (M3_k - M2_k M1_k), zero padded
+    double sm_c0 = 0.0, sm_v0 = 0.0, sm_z = 0.0, sm_rho = 0.0, sm_spread = 0.0;  // sums, calibrated z at corpus rank sm_rho, its spread
+    bool sm_ok = false;
+    int seed_model = 1;      // PN_OPT_SEED_MODEL: 1 (default) use it where it was accepted, 0 never
     // state that queries on a shared `const pn_index *` update: internally synchronised by `mu`
     struct Shared {
         std::mutex mu;
@@ -227,6 +234,7 @@ struct pn_index {
         unsigned next_rec = 0;
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
+        bool seed_model_off = false;  // a call seeded by the model left too many queries unproven: back to the scout (sticky)
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
         // the reference's ball tree, built on first use of the introspection API (tree.cpp): published once, built under
         // tree_mu -- never under `mu`, which every query takes (an O(n d log n) host build must not block them)
@@ -386,6 +394,8 @@ static std::atomic<int> &bf16_hw_state(int device) {
 }
 constexpr float kBf16SelftestLimit = 0.02f;  // of the allowance (measured on gfx950: <= 0.0016)
 
+template <typename RT>
+static int seed_model_build(pn_index *ix, const RT *rows, hipStream_t s);
 template <typename T>
 static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStream_t s) {
     // d_src: device rows [n][row_stride] (inner stride 1) -> padded layout + norms (+ the filter tiers' images).
@@ -519,6 +529,11 @@ static int finish_index(pn_index *ix, const T *d_src, size_t row_stride, hipStre
             ix->d_img = nullptr;
             ix->bf16_ci = false;
         }
+    }
+    if (cosine) {
+        if (nrm.p) PNCHK(seed_model_build<double>(ix, (const double *)nrm.p, s));  // (over the normalised rows)
+    } else {
+        PNCHK(seed_model_build<T>(ix, (const T *)ix->d_pts, s));
     }
     return PN_OK;
 }
@@ -697,6 +712,7 @@ extern "C" void pn_index_destroy(pn_index *ix) {
     if (ix->d_pts) (void)hipFree(ix->d_pts);
     if (ix->d_img) (void)hipFree(ix->d_img);
     if (ix->d_mu) (void)hipFree(ix->d_mu);
+    if (ix->d_smodel) (void)hipFree(ix->d_smodel);
     if (ix->d_norm) (void)hipFree(ix->d_norm);
     if (ix->d_cnorm) (void)hipFree(ix->d_cnorm);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
@@ -802,7 +818,10 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
         // -- widen it, then turn the tier off (sticky; takes effect from the next call on)
         const size_t nf = *r.h_nflag;
 #if !defined(PN_DIAG_BF_NOSLOW) && !defined(PN_DIAG_BF_NOSTORE) && !defined(PN_DIAG_BF_NOBARRIER) && !defined(PN_DIAG_BF_NOWAIT) && !defined(PN_DIAG_BF_NOAPPEND)  // timing-only builds flag queries by design
-        if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
+        // (a call seeded by the index's model instead of a scout launch: more than one query in 128 unproven means the
+        // model does not fit these queries -- back to the scout, for good; the plan itself is not to blame)
+        if (r.model_seed && nf * 128 > r.nq && r.nq >= 64) sh.seed_model_off = true;
+        else if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
 #else
         (void)nf;
 #endif
@@ -842,7 +861,7 @@ static int rec_begin(const pn_index *ix, uint64_t call_id, size_t nq, CallRec **
     r.nq = nq;
     r.call_id = call_id;
     r.prof = ix->profile;
-    r.two_launches = r.has_flag = r.bf16_tier = r.hot = false;
+    r.two_launches = r.has_flag = r.bf16_tier = r.hot = r.model_seed = false;
     r.busy = true;
     *r.h_nflag = 0;
     *out = &r;
@@ -881,7 +900,7 @@ extern "C" int pn_index_info(const pn_index *ix, pn_info *out) {
     out->mfma_eligible = ix->mfma_ok ? 1 : 0;
     out->bf16_eligible = ix->bf16_ok ? 1 : 0;
     out->bf16_layout = !ix->bf16_ok ? 0 : ix->bf16_ci ? 2 : 1;
-    out->reserved = 0;
+    out->seed_model = ix->sm_ok ? 1 : 0;
     return PN_OK;
 }
 
@@ -921,6 +940,10 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
         case PN_OPT_BF16_WAVES:
             if (value != 0 && value != 4 && value != 8) return fail(PN_ERR_INVALID, "bad wave count (0, 4 or 8)");
             ix->bf16_waves = (int)value;
+            return PN_OK;
+        case PN_OPT_SEED_MODEL:
+            if (value != 0 && value != 1) return fail(PN_ERR_INVALID, "bad seed-model switch (0 or 1)");
+            ix->seed_model = (int)value;
             return PN_OK;
         default: return fail(PN_ERR_INVALID, "unknown option %d", option);
     }
@@ -1216,9 +1239,21 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // Experiment knobs of the planner (tools/ sweeps): read from the environment ONCE per process and validated -- the
 // planner runs for every query chunk, incl. the one-point-per-call path, and a stray or malformed variable must not
 // feed NaN or negative numbers into plan geometry.  0 = not set.
+// z with P(N(0,1) > z) = p (0 < p < 0.5), by bisection on erfc -- planning-time only
+static double normal_tail_z(double p) {
+    if (!(p > 0.0)) return 9.0;
+    if (p >= 0.5) return 0.0;
+    double lo = 0.0, hi = 9.0;
+    for (int i = 0; i < 60; ++i) {
+        const double mid = 0.5 * (lo + hi);
+        if (0.5 * std::erfc(mid / 1.4142135623730951) > p) lo = mid; else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
 struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
-    size_t sh_min_run = 0, wide_per_tile = 0;
+    size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0;
+    double model_dz = 0.0;
     bool debug = false;
 };
 static const PlanKnobs &plan_knobs() {
@@ -1235,11 +1270,136 @@ static const PlanKnobs &plan_knobs() {
         v.scout_cap = num("PN_EXP_SCOUT_CAP", 1.0, 64.0);
         v.sh_min_run = (size_t)num("PN_EXP_SH_MIN_RUN", 1.0, 1.0e6);
         v.wide_per_tile = (size_t)num("PN_EXP_WIDE_PER_TILE", 1.0, 32.0);
+        v.model_kmax = (size_t)num("PN_EXP_MODEL_KMAX", 1.0, 1024.0);
+        v.model_dz = num("PN_EXP_MODEL_DZ", -2.0, 2.0);
         v.debug = getenv("PN_DEBUG_PLAN") != nullptr;
         return v;
     }();
     return k;
 }
+
+// Seed model (round 4; VERDICT r3: "a per-index seed model fitted at build time from corpus rows used as pseudo-queries").
+// Per-dimension moments of the translated corpus give, for any query, the mean and the variance of the filter's bound
+// L'(q, .) over the corpus rows (Bf16SeedModel in bf16_filter.hip); a starting threshold is then mean - z sqrt(var).
+// z is not derived but CALIBRATED: 256 corpus rows (at a constant stride) are run through the scout kernel as queries --
+// 128 segments, a twentieth of the corpus, the seed of rank 9 of that sample, i.e. corpus rank sm_rho -- and every one of
+// them yields the z its scout seed corresponds to.  The model is accepted only when those z agree: a normal tail's
+// log-rank moves by (z + 1/z) dz, and the standard deviation of that over the calibration queries must stay within
+// kSeedModelSpread (0.5: the seeds' corpus ranks within a factor 1.65 of each other at one sigma).  Uniform-like corpora
+// pass (1M x 128 uniform: 0.27), clustered ones do not (40 Gaussian clusters of different widths: 1.65) and keep the scout.  A threshold is never a
+// correctness matter (the proof of the re-rank decides; an unproven query goes to the next tier) -- only a matter of
+// which tier answers, so a model that misbehaves later switches itself off (rec_resolve: seed_model_off).
+constexpr double kSeedModelSpread = 0.5;
+static inline float host_s2f(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+template <typename T>  // T: element type of `rows` [n_pad][ld] -- the index's own rows, or the f64 normalised rows (Cosine)
+static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
+    ix->sm_ok = false;
+    const int dim = (int)ix->dim;
+    if (!ix->bf16_ok || !ix->d_img || bf16_is_wide(dim) || ix->n < 100000 || ix->seed_model == 0) return PN_OK;
+    constexpr size_t NQ = 256;
+    constexpr int NSEG = 128, RANK = 9;  // (one query tile of 256: NSEG workgroups)
+    const size_t r_tiles = (ix->n + 63) / 64, run_len = r_tiles / NSEG;
+    size_t t = (size_t)(0.05 * (double)r_tiles / NSEG + 0.5);
+    if (t > run_len / 4) t = run_len / 4;
+    if (t < 1) return PN_OK;
+    const double frac = (double)(t * NSEG) / (double)r_tiles;
+    const size_t ld = ix->ld, cells = NQ * (size_t)NSEG, words = cells * 2 * (size_t)bf16_scout_list();
+    DevTmp mom, qrows, bq, qn, qbad, lists, seeds, keys, cnt, tau;
+    HIPCHK(mom.alloc(4 * (size_t)dim * sizeof(double)));
+    HIPCHK(qrows.alloc(NQ * ld * sizeof(T)));
+    HIPCHK(bq.alloc(bf16_query_bytes(NQ, dim, ix->bf16_ci)));
+    HIPCHK(qn.alloc(NQ * sizeof(double)));
+    HIPCHK(qbad.alloc(NQ * sizeof(uint32_t)));
+    HIPCHK(lists.alloc(words * sizeof(float)));
+    HIPCHK(seeds.alloc(NQ * sizeof(uint32_t)));
+    HIPCHK(keys.alloc(cells * 64 * 8));
+    HIPCHK(cnt.alloc(cells * sizeof(uint32_t)));
+    HIPCHK(tau.alloc(cells * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(mom.p, 0, 4 * (size_t)dim * sizeof(double), s));
+    HIPCHK(launch_bf16_column_moments<T>(rows, ix->d_mu, ix->n, dim, ld, (double *)mom.p, s));
+    const size_t stride = ix->n / NQ;
+    HIPCHK(hipMemcpy2DAsync(qrows.p, ld * sizeof(T), (const char *)rows + (stride / 2) * ld * sizeof(T),
+                            stride * ld * sizeof(T), ld * sizeof(T), NQ, hipMemcpyDeviceToDevice, s));
+    HIPCHK(launch_bf16_pack_queries<T>((const T *)qrows.p, ix->d_mu, NQ, NQ, dim, ld, bq.p, (double *)qn.p,
+                                       (uint32_t *)qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
+    CandBuf cb{};
+    cb.keys = keys.p;
+    cb.idx = (uint32_t *)keys.p + 1;
+    cb.idx_stride = 2;
+    cb.cnt = (uint32_t *)cnt.p;
+    cb.tau = tau.p;
+    cb.nq_pad = NQ;
+    cb.nseg = NSEG;
+    cb.cap = 64;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)lists.p, (int)0x7F800000u, words, s));
+    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, (int)(NQ / 256) * NSEG, 1, (int)t, nullptr, false,
+                              (float *)lists.p, ix->bf16_ci, s, nullptr));
+    HIPCHK(launch_bf16_seed((const float *)lists.p, NQ, NSEG, RANK, (uint32_t *)seeds.p, s, NQ));
+    std::vector<double> h_mom(4 * (size_t)dim);
+    std::vector<T> h_q(NQ * ld);
+    std::vector<float> h_mu((size_t)dim);
+    std::vector<uint32_t> h_seed(NQ);
+    HIPCHK(hipMemcpyAsync(h_mom.data(), mom.p, h_mom.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_q.data(), qrows.p, h_q.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_mu.data(), ix->d_mu, h_mu.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_seed.data(), seeds.p, NQ * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const double inv_n = 1.0 / (double)ix->n;
+    std::vector<float> h_model(3 * ld, 0.0f);
+    double c0 = 0.0, v0 = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        const double m1 = h_mom[k] * inv_n, m2 = h_mom[dim + k] * inv_n, m3 = h_mom[2 * (size_t)dim + k] * inv_n,
+                     m4 = h_mom[3 * (size_t)dim + k] * inv_n;
+        h_model[k] = (float)m1;
+        h_model[ld + k] = (float)(4.0 * (m2 - m1 * m1));
+        h_model[2 * ld + k] = (float)(4.0 * (m3 - m2 * m1));
+        c0 += m2;
+        v0 += m4 - m2 * m2;
+    }
+    if (!(c0 > 0.0) || !(v0 > 0.0) || !std::isfinite(c0) || !std::isfinite(v0)) return PN_OK;
+    // every calibration query's z, in the arithmetic of the pack kernel (f64 over the f32 model words)
+    double zs = 0.0, zss = 0.0;
+    size_t used = 0;
+    for (size_t q = 0; q < NQ; ++q) {
+        const float sd = host_s2f(h_seed[q]);
+        if (!std::isfinite(sd)) continue;
+        double mean = 0.0, var = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double c = (double)h_q[q * ld + k] - (double)h_mu[k];
+            mean += c * (double)h_model[k];
+            var += c * (c * (double)h_model[ld + k] - (double)h_model[2 * ld + k]);
+        }
+        var += v0;
+        if (!(var > 0.0)) continue;
+        const double z = (c0 - 2.0 * mean - (double)sd) / std::sqrt(var);
+        zs += z;
+        zss += z * z;
+        ++used;
+    }
+    if (used < NQ * 3 / 4) return PN_OK;
+    const double zm = zs / (double)used, zv = zss / (double)used - zm * zm;
+    const double sd_z = std::sqrt(zv > 0.0 ? zv : 0.0);
+    ix->sm_c0 = c0;
+    ix->sm_v0 = v0;
+    ix->sm_z = zm;
+    ix->sm_rho = (double)RANK / frac;
+    ix->sm_spread = zm > 0.0 ? (zm + 1.0 / zm) * sd_z : 1e9;
+    if (plan_knobs().debug)
+        std::fprintf(stderr, "[pn seed model] n %zu dim %d: z %.4f +- %.4f (log-rank spread %.4f) at corpus rank %.1f, c0 %.6g v0 %.6g\n",
+                     ix->n, dim, zm, sd_z, ix->sm_spread, ix->sm_rho, c0, v0);
+    if (!(zm > 1.0) || !(ix->sm_spread <= kSeedModelSpread)) return PN_OK;
+    HIPCHK(hipMalloc((void **)&ix->d_smodel, h_model.size() * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(ix->d_smodel, h_model.data(), h_model.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ix->sm_ok = true;
+    return PN_OK;
+}
+
 struct Bf16Plan {
     int n_wg, split, nseg, kp, cap, scout_max;
     bool ok, aligned;
@@ -1252,6 +1412,8 @@ struct Bf16Plan {
     // shared thresholds (bf16_filter.hip): refresher workgroups behind the n_wg main ones, rank of the shared threshold
     int n_refresh, sh_rank;
     int first_eval;  // candidates the re-rank evaluates in its first round (the plan's R, rounded up)
+    bool model_seed;  // thresholds from the index's seed model: no scout launch (narrow rows, small k)
+    double model_z;   // its z for this k
 };
 // Wide rows: one workgroup per CU at a time (128 KiB of LDS), a whole number of workgroups per query tile: every cell
 // then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
@@ -1518,6 +1680,20 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // queries (tools/sh_fallback_rate.py): unproven queries 4 without shared thresholds (a segment's k' overflows),
     // 4 at r = 56 .. 80, 5 at r = 48; r = 40: 5 10^-5, r = 32: 3 10^-3.
     p.first_eval = (int)std::ceil(R);
+    // Seed model (seed_model_build): a plan that would launch the shared scout, on an index whose model was accepted at
+    // build time, for k <= 128 (measured at k = 1, 10, 100: profiles/r04_seed_model_ab.log) -- the thresholds then come
+    // from the query pack kernel and the scout launch is not made.
+    // The model's z was calibrated at corpus rank sm_rho; this k aims where the scout's seed lands (~7 R) and moves z by
+    // the difference of the normal quantiles of the two ranks.
+    p.model_seed = false;
+    p.model_z = 0.0;
+    if (p.shared_scout && ix->sm_ok && ix->seed_model != 0 && !ix->sh.seed_model_off &&
+        kout <= (plan_knobs().model_kmax ? plan_knobs().model_kmax : (size_t)128) && ix->n >= 100000) {
+        const double rho_t = (double)p.seed_rank * (double)r_tiles / ((double)p.scout_tiles * (double)per_tile);
+        p.model_z = ix->sm_z + (normal_tail_z(rho_t / (double)ix->n) - normal_tail_z(ix->sm_rho / (double)ix->n));
+        p.model_z += plan_knobs().model_dz;  // experiments only
+        p.model_seed = p.model_z > 1.0 && p.model_z < 8.0;
+    }
     p.n_refresh = 0;
     p.sh_rank = 0;
     if (p.shared_scout && p.aligned && ix->shared_tau != 0 && bf16_shared_supported(p.cap)) {
@@ -1536,9 +1712,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     }
     if (plan_knobs().debug)  // development aid: what a call was planned as
         fprintf(stderr, "bf16_plan: n %zu q_tiles %zu k %zu R %.0f: n_wg %d per_tile %zu split %d nseg %d kp %d cap %d aligned %d "
-                        "shared_scout %d scout_tiles %d seed_rank %d scout_max %d n_refresh %d sh_rank %d\n",
+                        "shared_scout %d scout_tiles %d seed_rank %d scout_max %d n_refresh %d sh_rank %d model_seed %d z %.3f\n",
                 ix->n, q_tiles, kout, R, p.n_wg, per_tile, p.split, p.nseg, p.kp, p.cap, (int)p.aligned, (int)p.shared_scout,
-                p.scout_tiles, p.seed_rank, p.scout_max, p.n_refresh, p.sh_rank);
+                p.scout_tiles, p.seed_rank, p.scout_max, p.n_refresh, p.sh_rank, (int)p.model_seed, p.model_z);
     return p;
 }
 // f32 MFMA filter -> exact re-rank + proof -> (second tier, enqueued by the caller) exact engine for flagged queries
@@ -1638,6 +1814,20 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
     PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));  // the re-rank lists the queries it could not prove here
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
+    // thresholds from the index's seed model: the query pack kernel writes them, no scout launch (bf16_plan)
+    const bool model = plan.model_seed && !plan.wide && ix->d_smodel;
+    Bf16SeedModel smd{};
+    if (model) {
+        PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
+        smd.m1 = ix->d_smodel;
+        smd.a = ix->d_smodel + ix->ld;
+        smd.b = ix->d_smodel + 2 * ix->ld;
+        smd.c0 = ix->sm_c0;
+        smd.v0 = ix->sm_v0;
+        smd.z = plan.model_z;
+        smd.seed_out = (uint32_t *)ws.w_seed.p;
+        if (rec) rec->model_seed = true;
+    }
     if (cosine) {
         // q~ = q / |q| in f64 (a query whose squared norm lies outside [2^-100, 2^100] becomes NaNs: the pack kernel
         // flags it and the exact engine answers it), then the f64 instantiation of the query pack
@@ -1646,14 +1836,16 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
                                             true, s));
         HIPCHK(launch_bf16_pack_queries<double>((const double *)ws.w_qnrm.p, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld,
                                                 ws.w_bq.p, (double *)ws.w_qn.p, (uint32_t *)ws.w_qbad.p, ix->bf16_ci,
-                                                ix->bf16_bmax, ix->bf16_dmax, s));
+                                                ix->bf16_bmax, ix->bf16_dmax, s, (double *)nullptr, 0, nullptr,
+                                                model ? &smd : nullptr));
     } else if (d_q_raw)
         HIPCHK(launch_bf16_pack_queries(d_q_raw, ix->d_mu, nq, nq_pad, (int)ix->dim, q_stride, ws.w_bq.p,
                                         (double *)ws.w_qn.p, (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax,
-                                        ix->bf16_dmax, s, const_cast<T *>(Qp), ix->ld, d_misc));
+                                        ix->bf16_dmax, s, const_cast<T *>(Qp), ix->ld, d_misc, model ? &smd : nullptr));
     else
         HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                        (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
+                                        (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s,
+                                        (T *)nullptr, 0, nullptr, model ? &smd : nullptr));
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_keys.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};
     cb.final_keep = bf16_cell_max((int)kp, cap, nseg, bf16_is_wide((int)ix->dim));  // what the re-rank sizes its LDS for
     cb.bf16_waves = ix->bf16_waves;
@@ -1665,7 +1857,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     if (prof) {
         HIPCHK(hipEventRecord(rec->ev[0], s));
         rec->hot = true;
-        rec->two_launches = plan.shared_scout;  // the dominant kernel runs twice per call: both launches are timed
+        rec->two_launches = plan.shared_scout && !model;  // the dominant kernel runs twice per call: both launches are timed
     }
     if (plan.shared_scout) {
         const size_t words = cells * 2 * (size_t)bf16_scout_list();
@@ -1678,7 +1870,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
                                            plan.scout_tiles, nullptr, false, (float *)ws.w_lists.p, s));
         // narrow rows, up to 32 segments: the main launch derives its starting thresholds from the lists itself (a
         // lane per query in its prologue) -- one launch less in the chain (the seed kernel: 17.6 us on a 10^4-query batch)
-        const bool seed_in_kernel = !plan.wide && bf16_seed_in_kernel(nseg) && plan.seed_rank <= bf16_scout_list();
+        const bool seed_in_kernel = !model && !plan.wide && bf16_seed_in_kernel(nseg) && plan.seed_rank <= bf16_scout_list();
         Bf16Shared seed{};
         if (seed_in_kernel) {
             seed.seed_lists = (const float *)ws.w_lists.p;
@@ -1686,11 +1878,11 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
             seed.seed_nq = (uint32_t)nq;
             seed.seed_words = (uint32_t *)ws.w_seed.p;
         }
-        if (!plan.wide)
+        if (!plan.wide && !model)
             HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, 1, plan.scout_tiles,
                                       nullptr, false, (float *)ws.w_lists.p, ix->bf16_ci, s,
                                       seed_in_kernel && plan.n_refresh > 0 ? &seed : nullptr));
-        if (!seed_in_kernel)
+        if (!seed_in_kernel && !model)
             HIPCHK(launch_bf16_seed((const float *)ws.w_lists.p, nq_pad, nseg, plan.seed_rank, (uint32_t *)ws.w_seed.p, s, nq));
         if (plan.wide)
             HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg, 0,

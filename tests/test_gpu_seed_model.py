@@ -1,0 +1,132 @@
+"""Seed model of the bf16 tier (round 4): k-NN calls with small k on a Euclidean index whose model was
+accepted at build take their starting thresholds from per-dimension moments of the corpus instead of a scout launch.
+
+A threshold never decides an answer -- the re-rank's proof does, and an unproven query goes to the next tier -- so the
+tests hold every answer against the exact engine (itself held against the oracle by tests/test_gpu_parity.py) with the
+model on and off, on the corpora the model accepts (uniform-like), on the ones it must refuse (clustered) and under
+queries the model has never seen the like of.
+"""
+import numpy as np
+import pytest
+
+from conftest import uniform
+
+pytestmark = pytest.mark.gpu
+
+PN_OPT_SEED_MODEL = 10
+
+
+def _exact(pn, tree, qs, k):
+    tree.set_engine("exact")
+    out = tree.query_batch(qs, k)
+    tree.set_engine("auto")
+    return out
+
+
+def _same(a, b):
+    return np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
+
+
+@pytest.mark.parametrize("dtype,dim", [(np.float32, 128), (np.float32, 64), (np.float64, 96)])
+def test_model_accepted_on_uniform_rows_answers_identical_on_and_off(pn, dtype, dim):
+    n, nq = 400_000, 4096
+    pts = uniform((n, dim), 4100 + dim, dtype)
+    qs = uniform((nq, dim), 4101 + dim, dtype)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible
+    assert tree.seed_model, "uniform rows: the calibration queries' z must agree"
+    for k in (1, 10, 32, 100):
+        want = _exact(pn, tree, qs, k)
+        tree.set_engine("bf16")
+        tree.set_option(PN_OPT_SEED_MODEL, 1)
+        tree.stats(reset=True)
+        on = tree.query_batch(qs, k)
+        st_on = tree.stats(reset=True)
+        tree.set_option(PN_OPT_SEED_MODEL, 0)
+        off = tree.query_batch(qs, k)
+        st_off = tree.stats(reset=True)
+        assert _same(on, want), (k, "seed model on")
+        assert _same(off, want), (k, "seed model off")
+        # the model's thresholds do the scout's job: few unproven queries, a comparable number of candidates
+        assert st_on["fallback_queries"] <= max(4, nq // 256), (k, st_on)
+        assert st_on["candidates"] <= 4 * st_off["candidates"] + 64 * nq, (k, st_on, st_off)
+    tree.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_model_on_a_cosine_index(pn, dtype):
+    """the model is fitted over the rows normalised in f64 (what the tier's images hold); Cosine answers identical with it
+    on and off, and to the exact scan"""
+    n, dim, nq = 300_000, 128, 2048
+    pts = uniform((n, dim), 4300, dtype) - dtype(0.3)
+    qs = uniform((nq, dim), 4301, dtype) - dtype(0.3)
+    tree = pn.BallTree.new(pts, pn.distance.Cosine())
+    assert tree.bf16_eligible and tree.seed_model
+    want = _exact(pn, tree, qs, 10)
+    tree.set_engine("bf16")
+    tree.stats(reset=True)
+    on = tree.query_batch(qs, 10)
+    st_on = tree.stats(reset=True)
+    tree.set_option(PN_OPT_SEED_MODEL, 0)
+    off = tree.query_batch(qs, 10)
+    assert _same(on, want) and _same(off, want)
+    assert st_on["fallback_queries"] <= nq // 64, st_on
+    tree.close()
+
+
+def test_model_refused_on_clustered_rows(pn):
+    rng = np.random.default_rng(77)
+    n, dim = 300_000, 64
+    centres = rng.normal(size=(40, dim)).astype(np.float32) * 4
+    scale = rng.uniform(0.02, 1.0, size=40).astype(np.float32)
+    lab = rng.integers(0, 40, size=n)
+    pts = centres[lab] + rng.normal(size=(n, dim)).astype(np.float32) * scale[lab, None]
+    qs = pts[rng.integers(0, n, size=1024)] + rng.normal(size=(1024, dim)).astype(np.float32) * 0.01
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible
+    assert not tree.seed_model, "clusters of different widths: no single z fits, the scout launch stays"
+    want = _exact(pn, tree, qs, 10)
+    tree.set_engine("bf16")
+    assert _same(tree.query_batch(qs, 10), want)
+    tree.close()
+
+
+def test_gaussian_rows_whatever_the_build_decided(pn):
+    """normal coordinates with per-dimension scales (skewed bound distribution): accepted or not, answers are exact and,
+    where the model is used, it leaves few queries to the next tier"""
+    rng = np.random.default_rng(78)
+    n, dim, nq = 300_000, 100, 2048
+    scales = rng.uniform(0.2, 2.0, size=dim).astype(np.float32)
+    pts = rng.normal(size=(n, dim)).astype(np.float32) * scales + np.float32(0.7)
+    qs = rng.normal(size=(nq, dim)).astype(np.float32) * scales + np.float32(0.7)
+    tree = pn.BallTree.euclidean(pts)
+    want = _exact(pn, tree, qs, 10)
+    tree.set_engine("bf16")
+    tree.stats(reset=True)
+    assert _same(tree.query_batch(qs, 10), want)
+    st = tree.stats(reset=True)
+    if tree.seed_model:
+        assert st["fallback_queries"] <= nq // 64, st
+    tree.close()
+
+
+def test_model_meets_queries_unlike_the_corpus(pn):
+    """accepted on uniform rows, then asked about queries far outside, on top of rows, and all alike: answers stay exact;
+    a batch the model serves badly switches it off for the handle (sticky), which the next call shows"""
+    n, dim = 400_000, 128
+    pts = uniform((n, dim), 4200, np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.seed_model
+    rng = np.random.default_rng(5)
+    far = uniform((1024, dim), 4201, np.float32) * np.float32(3.0) + np.float32(1.0)
+    on_rows = pts[rng.integers(0, n, size=1024)].copy()
+    alike = np.repeat(pts[7:8] * np.float32(0.999), 1024, axis=0)
+    corner = np.full((1024, dim), 0.5, np.float32) + rng.normal(size=(1024, dim)).astype(np.float32) * np.float32(0.01)
+    for name, qs in (("far", far), ("on_rows", on_rows), ("alike", alike), ("corner", corner)):
+        want = _exact(pn, tree, qs, 10)
+        tree.set_engine("bf16")
+        got = tree.query_batch(qs, 10)
+        assert _same(got, want), name
+        got = tree.query_batch(qs, 10)  # (possibly after the switch-off)
+        assert _same(got, want), name + " again"
+    tree.close()
