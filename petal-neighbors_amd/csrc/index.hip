@@ -192,6 +192,7 @@ struct CallRec {
 };
 constexpr int kCallRecs = 16;
 
+constexpr int kSeedModelGrid = 7;  // seed model: z calibrated at the corpus ranks 16, 32, ..., 1024
 struct pn_index {
     int device = 0;
     int elem_bytes = 4;
@@ -223,7 +224,9 @@ struct pn_index {
     // Seed model (round 4, seed_model_build): starting thresholds of a k-NN call from per-dimension moments of the corpus,
     // calibrated against the scout's own seeds at build time -- the calls it serves run WITHOUT the scout launch.
     float *d_smodel = nullptr;   // [3][ld] f32: M1_k | 4 (M2_k - M1_k^2) | 4 (M3_k - M2_k M1_k), zero padded
-    double sm_c0 = 0.0, sm_v0 = 0.0, sm_z = 0.0, sm_rho = 0.0, sm_spread = 0.0;  // sums, calibrated z at corpus rank sm_rho, its spread
+    double sm_c0 = 0.0, sm_v0 = 0.0;    // sum of the second moments / of the fourth central ones (query-independent parts)
+    double sm_zgrid[kSeedModelGrid] = {};  // calibrated z at the corpus ranks 16 << j
+    double sm_sigma = 0.0;              // standard deviation of ln(rank a model threshold really has / rank it aimed at)
     bool sm_ok = false;
     int seed_model = 1;      // PN_OPT_SEED_MODEL: 1 (default) use it where it was accepted, 0 never
     // state that queries on a shared `const pn_index *` update: internally synchronised by `mu`
@@ -234,6 +237,7 @@ struct pn_index {
         unsigned next_rec = 0;
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
+        int seed_model_widen = 0;     // calls seeded by the model left a few queries unproven: aim 1.5^this higher (sticky)
         bool seed_model_off = false;  // a call seeded by the model left too many queries unproven: back to the scout (sticky)
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
         // the reference's ball tree, built on first use of the introspection API (tree.cpp): published once, built under
@@ -821,6 +825,9 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
         // (a call seeded by the index's model instead of a scout launch: more than one query in 128 unproven means the
         // model does not fit these queries -- back to the scout, for good; the plan itself is not to blame)
         if (r.model_seed && nf * 128 > r.nq && r.nq >= 64) sh.seed_model_off = true;
+        else if (r.model_seed && nf * 1024 > r.nq && r.nq >= 256) {
+            if (++sh.seed_model_widen > 4) sh.seed_model_off = true;
+        }
         else if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
 #else
         (void)nf;
@@ -1239,21 +1246,11 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // Experiment knobs of the planner (tools/ sweeps): read from the environment ONCE per process and validated -- the
 // planner runs for every query chunk, incl. the one-point-per-call path, and a stray or malformed variable must not
 // feed NaN or negative numbers into plan geometry.  0 = not set.
-// z with P(N(0,1) > z) = p (0 < p < 0.5), by bisection on erfc -- planning-time only
-static double normal_tail_z(double p) {
-    if (!(p > 0.0)) return 9.0;
-    if (p >= 0.5) return 0.0;
-    double lo = 0.0, hi = 9.0;
-    for (int i = 0; i < 60; ++i) {
-        const double mid = 0.5 * (lo + hi);
-        if (0.5 * std::erfc(mid / 1.4142135623730951) > p) lo = mid; else hi = mid;
-    }
-    return 0.5 * (lo + hi);
-}
 struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
     size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0;
-    double model_dz = 0.0;
+    double model_dz = 0.0, model_rank = 0.0;
+    bool unaligned = false;
     bool debug = false;
 };
 static const PlanKnobs &plan_knobs() {
@@ -1272,6 +1269,8 @@ static const PlanKnobs &plan_knobs() {
         v.wide_per_tile = (size_t)num("PN_EXP_WIDE_PER_TILE", 1.0, 32.0);
         v.model_kmax = (size_t)num("PN_EXP_MODEL_KMAX", 1.0, 1024.0);
         v.model_dz = num("PN_EXP_MODEL_DZ", -2.0, 2.0);
+        v.model_rank = num("PN_EXP_MODEL_RANK", 1.0, 1024.0);
+        v.unaligned = getenv("PN_EXP_UNALIGNED") != nullptr;
         v.debug = getenv("PN_DEBUG_PLAN") != nullptr;
         return v;
     }();
@@ -1281,15 +1280,17 @@ static const PlanKnobs &plan_knobs() {
 // Seed model (round 4; VERDICT r3: "a per-index seed model fitted at build time from corpus rows used as pseudo-queries").
 // Per-dimension moments of the translated corpus give, for any query, the mean and the variance of the filter's bound
 // L'(q, .) over the corpus rows (Bf16SeedModel in bf16_filter.hip); a starting threshold is then mean - z sqrt(var).
-// z is not derived but CALIBRATED: 256 corpus rows (at a constant stride) are run through the scout kernel as queries --
-// 128 segments, a twentieth of the corpus, the seed of rank 9 of that sample, i.e. corpus rank sm_rho -- and every one of
-// them yields the z its scout seed corresponds to.  The model is accepted only when those z agree: a normal tail's
-// log-rank moves by (z + 1/z) dz, and the standard deviation of that over the calibration queries must stay within
-// kSeedModelSpread (0.5: the seeds' corpus ranks within a factor 1.65 of each other at one sigma).  Uniform-like corpora
-// pass (1M x 128 uniform: 0.27), clustered ones do not (40 Gaussian clusters of different widths: 1.65) and keep the scout.  A threshold is never a
-// correctness matter (the proof of the re-rank decides; an unproven query goes to the next tier) -- only a matter of
-// which tier answers, so a model that misbehaves later switches itself off (rec_resolve: seed_model_off).
-constexpr double kSeedModelSpread = 0.5;
+// z is not derived but CALIBRATED: 256 corpus rows (at a constant stride) are run through the scout kernel as queries
+// over the WHOLE corpus (128 segments; one query tile: a fortieth of a headline step), which leaves every query's ~3000
+// smallest bounds; the host reads them, drops the query's own row and notes, per query, the z that would have put the
+// threshold at the corpus ranks 16, 32, ..., 1024.  Their means over the queries are the grid a plan interpolates in
+// (no distributional assumption: the tail's shape is measured), and what the model gets wrong per query is measured too:
+// sm_sigma = standard deviation of ln(rank the model's threshold really has / rank it aimed at) at rank 64.  The model is
+// accepted when sm_sigma <= kSeedModelSigma: uniform-like corpora pass, clustered ones do not and keep the scout launch.
+// A threshold is never a correctness matter (the re-rank's proof decides; an unproven query goes to the next tier), only
+// a matter of which tier answers, so a model that misbehaves later first aims higher, then switches itself off
+// (rec_resolve: seed_model_widen, seed_model_off).
+constexpr double kSeedModelSigma = 0.35;
 static inline float host_s2f(uint32_t k) {
     const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
     float f;
@@ -1302,21 +1303,17 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     const int dim = (int)ix->dim;
     if (!ix->bf16_ok || !ix->d_img || bf16_is_wide(dim) || ix->n < 100000 || ix->seed_model == 0) return PN_OK;
     constexpr size_t NQ = 256;
-    constexpr int NSEG = 128, RANK = 9;  // (one query tile of 256: NSEG workgroups)
-    const size_t r_tiles = (ix->n + 63) / 64, run_len = r_tiles / NSEG;
-    size_t t = (size_t)(0.05 * (double)r_tiles / NSEG + 0.5);
-    if (t > run_len / 4) t = run_len / 4;
-    if (t < 1) return PN_OK;
-    const double frac = (double)(t * NSEG) / (double)r_tiles;
-    const size_t ld = ix->ld, cells = NQ * (size_t)NSEG, words = cells * 2 * (size_t)bf16_scout_list();
-    DevTmp mom, qrows, bq, qn, qbad, lists, seeds, keys, cnt, tau;
+    constexpr int NSEG = 128;  // (one query tile of 256: NSEG workgroups)
+    const size_t r_tiles = (ix->n + 63) / 64;
+    const size_t per = 2 * (size_t)bf16_scout_list();
+    const size_t ld = ix->ld, cells = NQ * (size_t)NSEG, words = cells * per;
+    DevTmp mom, qrows, bq, qn, qbad, lists, keys, cnt, tau;
     HIPCHK(mom.alloc(4 * (size_t)dim * sizeof(double)));
     HIPCHK(qrows.alloc(NQ * ld * sizeof(T)));
     HIPCHK(bq.alloc(bf16_query_bytes(NQ, dim, ix->bf16_ci)));
     HIPCHK(qn.alloc(NQ * sizeof(double)));
     HIPCHK(qbad.alloc(NQ * sizeof(uint32_t)));
     HIPCHK(lists.alloc(words * sizeof(float)));
-    HIPCHK(seeds.alloc(NQ * sizeof(uint32_t)));
     HIPCHK(keys.alloc(cells * 64 * 8));
     HIPCHK(cnt.alloc(cells * sizeof(uint32_t)));
     HIPCHK(tau.alloc(cells * sizeof(uint32_t)));
@@ -1337,17 +1334,16 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     cb.nseg = NSEG;
     cb.cap = 64;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)lists.p, (int)0x7F800000u, words, s));
-    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, (int)(NQ / 256) * NSEG, 1, (int)t, nullptr, false,
-                              (float *)lists.p, ix->bf16_ci, s, nullptr));
-    HIPCHK(launch_bf16_seed((const float *)lists.p, NQ, NSEG, RANK, (uint32_t *)seeds.p, s, NQ));
+    // scout-only launch over every tile of every run (scout_max beyond any run's length): buffers are not touched
+    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, (int)(NQ / 256) * NSEG, 1, (int)(r_tiles / NSEG + 2),
+                              nullptr, false, (float *)lists.p, ix->bf16_ci, s, nullptr));
     std::vector<double> h_mom(4 * (size_t)dim);
     std::vector<T> h_q(NQ * ld);
-    std::vector<float> h_mu((size_t)dim);
-    std::vector<uint32_t> h_seed(NQ);
+    std::vector<float> h_mu((size_t)dim), h_lists(words);
     HIPCHK(hipMemcpyAsync(h_mom.data(), mom.p, h_mom.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_q.data(), qrows.p, h_q.size() * sizeof(T), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_mu.data(), ix->d_mu, h_mu.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_seed.data(), seeds.p, NQ * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_lists.data(), lists.p, words * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const double inv_n = 1.0 / (double)ix->n;
     std::vector<float> h_model(3 * ld, 0.0f);
@@ -1362,12 +1358,14 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
         v0 += m4 - m2 * m2;
     }
     if (!(c0 > 0.0) || !(v0 > 0.0) || !std::isfinite(c0) || !std::isfinite(v0)) return PN_OK;
-    // every calibration query's z, in the arithmetic of the pack kernel (f64 over the f32 model words)
-    double zs = 0.0, zss = 0.0;
+    // per calibration query: its model mean / deviation (the pack kernel's arithmetic: f64 over the f32 model words) and
+    // its smallest bounds in ascending order, its own row (the smallest of all) dropped
+    constexpr size_t TOP = 1500;
+    std::vector<double> qmean(NQ), qsd(NQ, 0.0);
+    std::vector<std::vector<float>> top(NQ);
+    std::vector<float> all(NSEG * per);
     size_t used = 0;
     for (size_t q = 0; q < NQ; ++q) {
-        const float sd = host_s2f(h_seed[q]);
-        if (!std::isfinite(sd)) continue;
         double mean = 0.0, var = 0.0;
         for (int k = 0; k < dim; ++k) {
             const double c = (double)h_q[q * ld + k] - (double)h_mu[k];
@@ -1375,24 +1373,48 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
             var += c * (c * (double)h_model[ld + k] - (double)h_model[2 * ld + k]);
         }
         var += v0;
-        if (!(var > 0.0)) continue;
-        const double z = (c0 - 2.0 * mean - (double)sd) / std::sqrt(var);
-        zs += z;
-        zss += z * z;
+        if (!(var > 0.0) || !std::isfinite(var) || !std::isfinite(mean)) continue;
+        for (size_t seg = 0; seg < (size_t)NSEG; ++seg)
+            std::memcpy(&all[seg * per], &h_lists[(seg * NQ + q) * per], per * sizeof(float));
+        const size_t keep = TOP + 1 < all.size() ? TOP + 1 : all.size();
+        std::partial_sort(all.begin(), all.begin() + (ptrdiff_t)keep, all.end());
+        if (!std::isfinite(all[keep - 1])) continue;  // (fewer rows than that: n >= 100000 rules it out)
+        top[q].assign(all.begin() + 1, all.begin() + (ptrdiff_t)keep);
+        qmean[q] = c0 - 2.0 * mean;
+        qsd[q] = std::sqrt(var);
         ++used;
     }
     if (used < NQ * 3 / 4) return PN_OK;
-    const double zm = zs / (double)used, zv = zss / (double)used - zm * zm;
-    const double sd_z = std::sqrt(zv > 0.0 ? zv : 0.0);
+    for (int j = 0; j < kSeedModelGrid; ++j) {
+        const size_t rho = (size_t)16 << j;
+        double zs = 0.0;
+        for (size_t q = 0; q < NQ; ++q)
+            if (qsd[q] > 0.0) zs += (qmean[q] - (double)top[q][rho - 1]) / qsd[q];
+        ix->sm_zgrid[j] = zs / (double)used;
+    }
+    // what the model gets wrong: thresholds aimed at rank 64 -- the rank each one really has among its query's bounds
+    const double z64 = ix->sm_zgrid[2];
+    double ls = 0.0, lss = 0.0;
+    for (size_t q = 0; q < NQ; ++q) {
+        if (!(qsd[q] > 0.0)) continue;
+        const float S = (float)(qmean[q] - z64 * qsd[q]);
+        const size_t cnt_below = (size_t)(std::lower_bound(top[q].begin(), top[q].end(), S) - top[q].begin());
+        const double l = std::log(((double)cnt_below + 0.5) / 64.0);
+        ls += l;
+        lss += l * l;
+    }
+    const double lm = ls / (double)used, lv = lss / (double)used - lm * lm;
     ix->sm_c0 = c0;
     ix->sm_v0 = v0;
-    ix->sm_z = zm;
-    ix->sm_rho = (double)RANK / frac;
-    ix->sm_spread = zm > 0.0 ? (zm + 1.0 / zm) * sd_z : 1e9;
+    ix->sm_sigma = std::sqrt(lv > 0.0 ? lv : 0.0);
+    bool mono = true;  // (z must fall as the rank grows)
+    for (int j = 1; j < kSeedModelGrid; ++j) mono = mono && ix->sm_zgrid[j] < ix->sm_zgrid[j - 1];
     if (plan_knobs().debug)
-        std::fprintf(stderr, "[pn seed model] n %zu dim %d: z %.4f +- %.4f (log-rank spread %.4f) at corpus rank %.1f, c0 %.6g v0 %.6g\n",
-                     ix->n, dim, zm, sd_z, ix->sm_spread, ix->sm_rho, c0, v0);
-    if (!(zm > 1.0) || !(ix->sm_spread <= kSeedModelSpread)) return PN_OK;
+        std::fprintf(stderr, "[pn seed model] n %zu dim %d: z at ranks 16..1024 = %.3f %.3f %.3f %.3f %.3f %.3f %.3f, log-rank "
+                             "error at rank 64: mean %.3f sigma %.3f; c0 %.6g v0 %.6g\n",
+                     ix->n, dim, ix->sm_zgrid[0], ix->sm_zgrid[1], ix->sm_zgrid[2], ix->sm_zgrid[3], ix->sm_zgrid[4],
+                     ix->sm_zgrid[5], ix->sm_zgrid[6], lm, ix->sm_sigma, c0, v0);
+    if (!mono || !(ix->sm_zgrid[kSeedModelGrid - 1] > 0.5) || !(ix->sm_sigma <= kSeedModelSigma)) return PN_OK;
     HIPCHK(hipMalloc((void **)&ix->d_smodel, h_model.size() * sizeof(float)));
     HIPCHK(hipMemcpyAsync(ix->d_smodel, h_model.data(), h_model.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1548,11 +1570,11 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     if (ix->opt_segments > 0 && q_tiles * (size_t)ix->opt_segments < cap_wg) cap_wg = q_tiles * (size_t)ix->opt_segments;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
-    if (q_tiles > 2) n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);  // (many query tiles: a grid run in rounds)
+    if (q_tiles > 2 && !plan_knobs().unaligned) n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);  // (many query tiles: a grid run in rounds)
     // a whole number of workgroups per query tile: each workgroup's slice is then ONE run.  A slice that straddles
     // a query-tile boundary is two runs, each with its own operand load, scout pass and buffer warm-up, and those
     // workgroups set the kernel's time (C2: 512 workgroups = 12.8 per tile 4.34 ms, 480 = 12 per tile 3.62 ms)
-    if (n_wg > q_tiles) n_wg = n_wg / q_tiles * q_tiles;
+    if (n_wg > q_tiles && !plan_knobs().unaligned) n_wg = n_wg / q_tiles * q_tiles;
     p.n_wg = (int)n_wg;
     // rows whose bound lies below the k-th neighbour's distance: ~1.2 k on benign data once the vectors are
     // translated by the corpus mean (measured: 11.8 for k = 10, 116 for k = 100); planned with a margin
@@ -1682,21 +1704,36 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     p.first_eval = (int)std::ceil(R);
     // Seed model (seed_model_build): a plan that would launch the shared scout, on an index whose model was accepted at
     // build time, for k <= 128 (measured at k = 1, 10, 100: profiles/r04_seed_model_ab.log) -- the thresholds then come
-    // from the query pack kernel and the scout launch is not made.
-    // The model's z was calibrated at corpus rank sm_rho; this k aims where the scout's seed lands (~7 R) and moves z by
-    // the difference of the normal quantiles of the two ranks.
+    // from the query pack kernel and the scout launch is not made.  Where to aim: a threshold must stay above the R
+    // relevant rows -- R + 5.5 sqrt(R) covers their spread (the shared thresholds' rank, measured below) -- times
+    // exp(4 sigma) for what the model gets wrong per query (sigma measured at build), times 1.5 per sticky widening
+    // step.  Unlike the scout's seed (rank ~7.5 R: its sample holds Poisson(1.2) of the relevant rows) the model has no
+    // sampling noise, so it starts every segment near the threshold it would end with: C2 kernel 2.32 -> 2.13 ms.
     p.model_seed = false;
     p.model_z = 0.0;
-    if (p.shared_scout && ix->sm_ok && ix->seed_model != 0 && !ix->sh.seed_model_off &&
+    if ((p.shared_scout || (plan_knobs().unaligned && p.ok && level == 0 && ix->filter_slots == 0)) && ix->sm_ok &&
+        ix->seed_model != 0 && !ix->sh.seed_model_off &&
         kout <= (plan_knobs().model_kmax ? plan_knobs().model_kmax : (size_t)128) && ix->n >= 100000) {
-        const double rho_t = (double)p.seed_rank * (double)r_tiles / ((double)p.scout_tiles * (double)per_tile);
-        p.model_z = ix->sm_z + (normal_tail_z(rho_t / (double)ix->n) - normal_tail_z(ix->sm_rho / (double)ix->n));
-        p.model_z += plan_knobs().model_dz;  // experiments only
-        p.model_seed = p.model_z > 1.0 && p.model_z < 8.0;
+        const double sig = ix->sm_sigma > 0.05 ? ix->sm_sigma : 0.05;
+        double rho_t = (R + 5.5 * std::sqrt(R)) * std::exp(4.0 * sig) * std::pow(1.5, (double)ix->sh.seed_model_widen);
+        if (plan_knobs().model_rank > 0.0) rho_t = plan_knobs().model_rank;  // experiments only
+        if (rho_t < 16.0) rho_t = 16.0;
+        const double top_rank = (double)(16u << (kSeedModelGrid - 1));
+        if (rho_t <= top_rank && rho_t * 50.0 <= (double)ix->n) {
+            const double x = std::log2(rho_t / 16.0);  // position in the grid (ranks 16 << j)
+            int j = (int)x;
+            if (j > kSeedModelGrid - 2) j = kSeedModelGrid - 2;
+            const double f = x - (double)j;
+            p.model_z = ix->sm_zgrid[j] * (1.0 - f) + ix->sm_zgrid[j + 1] * f + plan_knobs().model_dz;
+            p.model_seed = p.model_z > 0.5 && p.model_z < 12.0;
+        }
     }
     p.n_refresh = 0;
     p.sh_rank = 0;
-    if (p.shared_scout && p.aligned && ix->shared_tau != 0 && bf16_shared_supported(p.cap)) {
+    // (with thresholds from the seed model the segments start where sharing would only bring them later: measured on
+    // one device, C2: 2.09-2.11 ms with refreshers, 2.06-2.07 without -- sharing stays for explicit ranks and scouted plans)
+    if (p.shared_scout && p.aligned && ix->shared_tau != 0 && !(p.model_seed && ix->shared_tau == 1) &&
+        bf16_shared_supported(p.cap)) {
         const int slots = 2 * ix->n_cu - p.n_wg;
         const int rank = ix->shared_tau >= 2 ? ix->shared_tau : (int)std::ceil(R + 5.5 * std::sqrt(R));
         // (a refresher holds up to 512 keys of a query's union in registers -- and at k = 100 (r = 330, 128-slot buffers)
@@ -1914,6 +1951,9 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     } else if (plan.wide) {
         HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg,
                                        plan.scout_max, nullptr, false, nullptr, s));
+    } else if (model) {  // any partition: thresholds from the seed model, no scouting inside the runs
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, plan.split, 0,
+                                  (const uint32_t *)ws.w_seed.p, false, nullptr, ix->bf16_ci, s));
     } else {
         HIPCHK(launch_bf16_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, n_wg, plan.split,
                                   plan.scout_max, nullptr, false, nullptr, ix->bf16_ci, s));

@@ -342,6 +342,9 @@ def test_shared_thresholds_only_change_the_candidate_count(pn, oracle_mod):
         if mode == 2:  # a fresh index: a call that leaves > 1/16 of its queries unproven makes an index plan conservatively
             tree = pn.BallTree.euclidean(pts)  # (sticky), and r = 2 does exactly that -- so does r = 24 for a third of them
             tree.set_engine("bf16")
+        # (thresholds from the scout launch: with the index's seed model the default plan does not share at all --
+        # tests/test_gpu_seed_model.py covers the model, with and without an explicit sharing rank)
+        tree.set_option(_lib.PN_OPT_SEED_MODEL, 0)
         tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, mode)
         tree.stats(reset=True)
         for _ in range(3):  # consecutive calls on one workspace: the epoch of the published words changes every call
@@ -387,6 +390,7 @@ def test_shared_thresholds_below_the_kth_bound_never_prove_a_wrong_answer(pn, or
         assert tree.bf16_eligible
         tree.set_engine("bf16")
         tree.set_option(_lib.PN_OPT_SEGMENTS, 4)           # 4 segments x 859-tile runs: shared thresholds are planned
+        tree.set_option(_lib.PN_OPT_SEED_MODEL, 0)         # (scouted starting thresholds, as when the defect was found)
         tree.set_option(_lib.PN_OPT_SHARED_THRESHOLDS, rank)
         idx, dist = tree.query_batch(qs, k)
         st = tree.stats()

@@ -14,6 +14,7 @@ from conftest import uniform
 pytestmark = pytest.mark.gpu
 
 PN_OPT_SEED_MODEL = 10
+PN_OPT_SHARED_THRESHOLDS = 8
 
 
 def _exact(pn, tree, qs, k):
@@ -50,6 +51,34 @@ def test_model_accepted_on_uniform_rows_answers_identical_on_and_off(pn, dtype, 
         # the model's thresholds do the scout's job: few unproven queries, a comparable number of candidates
         assert st_on["fallback_queries"] <= max(4, nq // 256), (k, st_on)
         assert st_on["candidates"] <= 4 * st_off["candidates"] + 64 * nq, (k, st_on, st_off)
+    tree.close()
+
+
+def test_model_seeds_with_an_explicit_sharing_rank(pn):
+    """by default a plan seeded by the model does not share thresholds between segments (they start where sharing would
+    only bring them); an explicit PN_OPT_SHARED_THRESHOLDS rank keeps the refreshers on top of the model's seeds --
+    including ranks that cut below the k-th neighbour: answers never change"""
+    n, dim, nq, k = 1_200_000, 128, 3000, 10
+    pts, qs = uniform((n, dim), 3101, np.float32), uniform((nq, dim), 3102, np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.seed_model
+    want = _exact(pn, tree, qs, k)
+    seen = {}
+    for rank in (1, 44, 70, 8):
+        if rank == 8:
+            tree.close()
+            tree = pn.BallTree.euclidean(pts)  # (the unproven queries of rank 8 would switch things off for later calls)
+        tree.set_engine("bf16")
+        tree.set_option(PN_OPT_SHARED_THRESHOLDS, rank)
+        tree.stats(reset=True)
+        for _ in range(2):
+            got = tree.query_batch(qs, k)
+        st = tree.stats(reset=True)
+        seen[rank] = (st["fallback_queries"], round(st["candidates"] / st["queries"], 1))
+        assert _same(got, want), (rank, seen)
+    print("model seeds + sharing rank: (unproven, candidates per query)", seen)
+    assert seen[44][1] < seen[1][1], seen   # the refreshers did lower thresholds below the model's seeds
+    assert seen[8][0] > nq // 2, seen       # and an absurd rank sends most queries to the next tier
     tree.close()
 
 
