@@ -552,11 +552,13 @@ __global__ void bf16_pack_queries_kernel(const T *__restrict__ Q, const float *_
 template <typename T, bool QRY>
 __global__ void bf16_pack_wide8_kernel(const T *__restrict__ X, const float *__restrict__ mu, size_t n_valid,
                                        size_t n_rows_img, int dim, size_t ld, uint16_t *__restrict__ img,
-                                       double *__restrict__ qn, uint32_t *__restrict__ qbad, uint32_t *__restrict__ bad) {
+                                       double *__restrict__ qn, uint32_t *__restrict__ qbad, uint32_t *__restrict__ bad,
+                                       Bf16SeedModel sm) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t r = t >> 3;
     const int sub = (int)(t & 7);
     if (r >= n_rows_img) return;  // (whole groups of eight leave together)
+    double sm_mean = 0.0, sm_var = 0.0;  // (queries, seed model: see bf16_pack_queries8_kernel)
     const int n_slots = 8 * bf16_wide_nkc(dim) + (bf16_wide_has_x(dim) ? 2 : 0);
     const int E = bf16_extra_col(dim);
     const int gx0 = E >> 3, gx1 = (E + 4) >> 3;  // the slot(s) of the extra columns
@@ -601,6 +603,10 @@ __global__ void bf16_pack_wide8_kernel(const T *__restrict__ X, const float *__r
                     const double e = c - (double)xh;
                     en += e * e;
                     hn += (double)xh * (double)xh;
+                    if (QRY && sm.seed_out) {
+                        sm_mean += c * (double)sm.m1[k0 + j];
+                        sm_var += c * (c * (double)sm.a[k0 + j] - (double)sm.b[k0 + j]);
+                    }
                 }
             }
         }
@@ -658,10 +664,26 @@ __global__ void bf16_pack_wide8_kernel(const T *__restrict__ X, const float *__r
         }
         *reinterpret_cast<u4_ *>(img + bf_wide_at(r, 8 * g, dim)) = pack8(vx[w]);
     }
+    if (QRY && sm.seed_out) {
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            sm_mean += __shfl_xor(sm_mean, d);
+            sm_var += __shfl_xor(sm_var, d);
+        }
+    }
     if (sub == 0) {
         if (QRY) {
             qn[r] = ok ? s / kUp : 0.0;
             qbad[r] = ok ? 0u : 1u;
+            if (sm.seed_out) {  // starting threshold from the index's seed model; padding and bad queries: -inf
+                float sd = __uint_as_float(0xFF800000u);
+                if (in_rows && ok) {
+                    const double var = sm.v0 + sm_var;
+                    sd = f_up_signed(sm.c0 - 2.0 * sm_mean - sm.z * sqrt(var > 0.0 ? var : 0.0));
+                }
+                const uint32_t key = f2s(sd);
+                sm.seed_out[r] = (sd == sd && key != 0xFFFFFFFFu && in_rows && ok) ? key + 1u : f2s(__uint_as_float(0xFF800000u));
+            }
         } else if (in_rows && !ok) {
             atomicOr(bad, 1u);
         }
@@ -3221,7 +3243,7 @@ hipError_t launch_bf16_pack_corpus(const T *P, const float *mu, size_t n, int di
 #ifndef PN_DIAG_BF_PACK1
     if (wide) {  // rows is a multiple of 256
         hipLaunchKernelGGL((bf16_pack_wide8_kernel<T, false>), dim3((unsigned)(rows * 8 / 256)), dim3(256), 0, s, P, mu, n, rows,
-                           dim, ld, static_cast<uint16_t *>(img), (double *)nullptr, (uint32_t *)nullptr, bad);
+                           dim, ld, static_cast<uint16_t *>(img), (double *)nullptr, (uint32_t *)nullptr, bad, Bf16SeedModel{});
         return hipGetLastError();
     }
     if (!wide) {  // rows is a multiple of 64: whole blocks of 256 threads = 32 rows
@@ -3251,7 +3273,7 @@ hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size
     if ((Qp || misc) && !bf16_pack_fused_supported(dim)) return hipErrorInvalidValue;
     Bf16SeedModel sm{};
     if (smp) sm = *smp;
-    if (sm.seed_out && (bf16_is_wide(dim) || !sm.m1 || !sm.a || !sm.b)) return hipErrorInvalidValue;
+    if (sm.seed_out && (!sm.m1 || !sm.a || !sm.b)) return hipErrorInvalidValue;
 #ifndef PN_DIAG_BF_PACKQ1
     if (!bf16_is_wide(dim)) {  // nq_pad is a multiple of 256: whole blocks
         hipLaunchKernelGGL(bf16_pack_queries8_kernel<T>, dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq,
@@ -3260,14 +3282,14 @@ hipError_t launch_bf16_pack_queries(const T *Q, const float *mu, size_t nq, size
         return hipGetLastError();
     }
 #endif
-    if (sm.seed_out) return hipErrorInvalidValue;  // (model seeds come from the eight-lanes-per-query kernel only)
 #ifndef PN_DIAG_BF_PACK1
     if (bf16_is_wide(dim) && !ci && nq_pad % 32 == 0) {  // (nq_pad is a multiple of 256 for wide rows)
         hipLaunchKernelGGL((bf16_pack_wide8_kernel<T, true>), dim3((unsigned)(nq_pad * 8 / 256)), dim3(256), 0, s, Q, mu, nq, nq_pad,
-                           dim, ld, static_cast<uint16_t *>(B), qn, qbad, (uint32_t *)nullptr);
+                           dim, ld, static_cast<uint16_t *>(B), qn, qbad, (uint32_t *)nullptr, sm);
         return hipGetLastError();
     }
 #endif
+    if (sm.seed_out) return hipErrorInvalidValue;  // (model seeds come from the eight-lanes-per-query kernels only)
     hipLaunchKernelGGL(bf16_pack_queries_kernel<T>, dim3((unsigned)((nq_pad + 127) / 128)), dim3(128), 0, s, Q, mu, nq, nq_pad,
                        dim, ld, bf16_ks_for(dim, ci), static_cast<uint16_t *>(B), qn, qbad, bf16_is_wide(dim) ? 1 : 0,
                        ci ? 1 : 0, bmax, dmax);

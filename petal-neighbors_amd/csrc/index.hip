@@ -1301,10 +1301,12 @@ template <typename T>  // T: element type of `rows` [n_pad][ld] -- the index's o
 static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     ix->sm_ok = false;
     const int dim = (int)ix->dim;
-    if (!ix->bf16_ok || !ix->d_img || bf16_is_wide(dim) || ix->n < 100000 || ix->seed_model == 0) return PN_OK;
+    if (!ix->bf16_ok || !ix->d_img || ix->n < 100000 || ix->seed_model == 0) return PN_OK;
+    const bool wide = bf16_is_wide(dim);
     constexpr size_t NQ = 256;
-    constexpr int NSEG = 128;  // (one query tile of 256: NSEG workgroups)
-    const size_t r_tiles = (ix->n + 63) / 64;
+    constexpr int NWG = 128;                 // one query tile of 256: NWG workgroups
+    const int NSEG = wide ? 2 * NWG : NWG;   // (wide rows: a workgroup's two row halves are two segments)
+    const size_t r_tiles = wide ? (ix->n + 255) / 256 : (ix->n + 63) / 64;
     const size_t per = 2 * (size_t)bf16_scout_list();
     const size_t ld = ix->ld, cells = NQ * (size_t)NSEG, words = cells * per;
     DevTmp mom, qrows, bq, qn, qbad, lists, keys, cnt, tau;
@@ -1335,8 +1337,12 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     cb.cap = 64;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)lists.p, (int)0x7F800000u, words, s));
     // scout-only launch over every tile of every run (scout_max beyond any run's length): buffers are not touched
-    HIPCHK(launch_bf16_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, (int)(NQ / 256) * NSEG, 1, (int)(r_tiles / NSEG + 2),
-                              nullptr, false, (float *)lists.p, ix->bf16_ci, s, nullptr));
+    if (wide)
+        HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, NWG, (int)(r_tiles / NWG + 2), nullptr, false,
+                                       (float *)lists.p, s));
+    else
+        HIPCHK(launch_bf16_filter(ix->d_img, ix->n, dim, bq.p, 24, cb, NWG, 1, (int)(r_tiles / NWG + 2), nullptr, false,
+                                  (float *)lists.p, ix->bf16_ci, s, nullptr));
     std::vector<double> h_mom(4 * (size_t)dim);
     std::vector<T> h_q(NQ * ld);
     std::vector<float> h_mu((size_t)dim), h_lists(words);
@@ -1363,7 +1369,7 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     constexpr size_t TOP = 1500;
     std::vector<double> qmean(NQ), qsd(NQ, 0.0);
     std::vector<std::vector<float>> top(NQ);
-    std::vector<float> all(NSEG * per);
+    std::vector<float> all((size_t)NSEG * per);
     size_t used = 0;
     for (size_t q = 0; q < NQ; ++q) {
         double mean = 0.0, var = 0.0;
@@ -1441,6 +1447,26 @@ struct Bf16Plan {
 // then has exactly one writer (no memsets, exact segment count) and the workgroups of different query tiles walk the
 // same rows at the same time, which is what lets them share corpus tiles in L2 (1M x 768, 10^4 queries: 240 aligned
 // workgroups 15.0 ms, 256 balanced ones 15.6 ms).  The kernel itself takes any number of workgroups.
+// Seed model in a plan (see bf16_plan): sets model_seed / model_z when the index's model serves this call
+static void plan_seed_model(const pn_index *ix, Bf16Plan &p, double R, size_t kout, bool eligible) {
+    p.model_seed = false;
+    p.model_z = 0.0;
+    if (!eligible || !ix->sm_ok || ix->seed_model == 0 || ix->sh.seed_model_off ||
+        kout > (plan_knobs().model_kmax ? plan_knobs().model_kmax : (size_t)128) || ix->n < 100000)
+        return;
+    const double sig = ix->sm_sigma > 0.05 ? ix->sm_sigma : 0.05;
+    double rho_t = (R + 5.5 * std::sqrt(R)) * std::exp(4.0 * sig) * std::pow(1.5, (double)ix->sh.seed_model_widen);
+    if (plan_knobs().model_rank > 0.0) rho_t = plan_knobs().model_rank;  // experiments only
+    if (rho_t < 16.0) rho_t = 16.0;
+    const double top_rank = (double)(16u << (kSeedModelGrid - 1));
+    if (rho_t > top_rank || rho_t * 50.0 > (double)ix->n) return;
+    const double x = std::log2(rho_t / 16.0);  // position in the grid (ranks 16 << j)
+    int j = (int)x;
+    if (j > kSeedModelGrid - 2) j = kSeedModelGrid - 2;
+    const double f = x - (double)j;
+    p.model_z = ix->sm_zgrid[j] * (1.0 - f) + ix->sm_zgrid[j + 1] * f + plan_knobs().model_dz;
+    p.model_seed = p.model_z > 0.5 && p.model_z < 12.0;
+}
 static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, int level) {
     Bf16Plan p{};
     p.wide = true;
@@ -1525,6 +1551,12 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
     }
 #endif
     p.first_eval = (int)std::ceil(R);
+    plan_seed_model(ix, p, R, kout, p.shared_scout);
+    if (plan_knobs().debug)
+        fprintf(stderr, "bf16_plan_wide: n %zu q_tiles %zu k %zu R %.0f: n_wg %d per_tile %d nseg %d kp %d cap %d shared_scout %d "
+                        "scout_tiles %d seed_rank %d model_seed %d z %.3f\n",
+                ix->n, q_tiles, kout, R, p.n_wg, p.per_tile, p.nseg, p.kp, p.cap, (int)p.shared_scout, p.scout_tiles, p.seed_rank,
+                (int)p.model_seed, p.model_z);
     return p;
 }
 // Narrow rows, enough work for every workgroup slot: a grid of c workgroups per query tile, run in rounds when it
@@ -1709,25 +1741,7 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // exp(4 sigma) for what the model gets wrong per query (sigma measured at build), times 1.5 per sticky widening
     // step.  Unlike the scout's seed (rank ~7.5 R: its sample holds Poisson(1.2) of the relevant rows) the model has no
     // sampling noise, so it starts every segment near the threshold it would end with: C2 kernel 2.32 -> 2.13 ms.
-    p.model_seed = false;
-    p.model_z = 0.0;
-    if ((p.shared_scout || (plan_knobs().unaligned && p.ok && level == 0 && ix->filter_slots == 0)) && ix->sm_ok &&
-        ix->seed_model != 0 && !ix->sh.seed_model_off &&
-        kout <= (plan_knobs().model_kmax ? plan_knobs().model_kmax : (size_t)128) && ix->n >= 100000) {
-        const double sig = ix->sm_sigma > 0.05 ? ix->sm_sigma : 0.05;
-        double rho_t = (R + 5.5 * std::sqrt(R)) * std::exp(4.0 * sig) * std::pow(1.5, (double)ix->sh.seed_model_widen);
-        if (plan_knobs().model_rank > 0.0) rho_t = plan_knobs().model_rank;  // experiments only
-        if (rho_t < 16.0) rho_t = 16.0;
-        const double top_rank = (double)(16u << (kSeedModelGrid - 1));
-        if (rho_t <= top_rank && rho_t * 50.0 <= (double)ix->n) {
-            const double x = std::log2(rho_t / 16.0);  // position in the grid (ranks 16 << j)
-            int j = (int)x;
-            if (j > kSeedModelGrid - 2) j = kSeedModelGrid - 2;
-            const double f = x - (double)j;
-            p.model_z = ix->sm_zgrid[j] * (1.0 - f) + ix->sm_zgrid[j + 1] * f + plan_knobs().model_dz;
-            p.model_seed = p.model_z > 0.5 && p.model_z < 12.0;
-        }
-    }
+    plan_seed_model(ix, p, R, kout, p.shared_scout || (plan_knobs().unaligned && p.ok && level == 0 && ix->filter_slots == 0));
     p.n_refresh = 0;
     p.sh_rank = 0;
     // (with thresholds from the seed model the segments start where sharing would only bring them later: measured on
@@ -1852,7 +1866,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
     PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));  // the re-rank lists the queries it could not prove here
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
     // thresholds from the index's seed model: the query pack kernel writes them, no scout launch (bf16_plan)
-    const bool model = plan.model_seed && !plan.wide && ix->d_smodel;
+    const bool model = plan.model_seed && ix->d_smodel;
     Bf16SeedModel smd{};
     if (model) {
         PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
@@ -1902,7 +1916,7 @@ static int run_bf16(const pn_index *ix, Workspace &ws, const Bf16Plan &plan, con
         PNCHK(ws.w_seed.ensure(nq_pad * sizeof(uint32_t)));
         if (!plan.aligned)
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_lists.p, (int)0x7F800000u, words, s));  // +inf: unused cells
-        if (plan.wide)
+        if (plan.wide && !model)
             HIPCHK(launch_bf16_wide_filter(ix->d_img, ix->n, (int)ix->dim, ws.w_bq.p, (int)kp, cb, plan.n_wg,
                                            plan.scout_tiles, nullptr, false, (float *)ws.w_lists.p, s));
         // narrow rows, up to 32 segments: the main launch derives its starting thresholds from the lists itself (a

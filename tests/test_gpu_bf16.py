@@ -214,8 +214,10 @@ def test_bf16_ineligible_index(pn):
     assert not tree.bf16_eligible
     with pytest.raises(Exception):
         tree.set_engine("bf16")
-    wide = pn.BallTree.euclidean(uniform((5000, 1030), 72))  # rows beyond 1024 columns: no bf16 tier
-    assert not wide.bf16_eligible
+    wide = pn.BallTree.euclidean(uniform((5000, 1030), 72))  # (round 4: the tier serves rows up to 4096 columns)
+    assert wide.bf16_eligible
+    wider = pn.BallTree.euclidean(uniform((600, 4100), 73))  # rows beyond 4096 columns: no bf16 tier
+    assert not wider.bf16_eligible
 
 
 def test_bf16_radius_mixed_density_falls_back_per_query(pn, oracle_mod):

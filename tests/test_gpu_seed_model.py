@@ -159,3 +159,22 @@ def test_model_meets_queries_unlike_the_corpus(pn):
         got = tree.query_batch(qs, 10)  # (possibly after the switch-off)
         assert _same(got, want), name + " again"
     tree.close()
+
+
+def test_model_on_wide_rows(pn):
+    """D = 768 (the K-chunked kernel): the model replaces the wide scout launch; answers identical on and off"""
+    n, dim, nq = 200_000, 768, 1024
+    pts = uniform((n, dim), 4400, np.float32)
+    qs = uniform((nq, dim), 4401, np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.bf16_eligible and tree.seed_model
+    want = _exact(pn, tree, qs, 10)
+    tree.set_engine("bf16")
+    tree.stats(reset=True)
+    on = tree.query_batch(qs, 10)
+    st_on = tree.stats(reset=True)
+    tree.set_option(PN_OPT_SEED_MODEL, 0)
+    off = tree.query_batch(qs, 10)
+    assert _same(on, want) and _same(off, want)
+    assert st_on["fallback_queries"] <= nq // 64, st_on
+    tree.close()
