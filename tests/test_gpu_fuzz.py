@@ -25,3 +25,13 @@ def test_random_sharded_handles_match_the_oracle(pn, oracle_mod, seed):
     rng = np.random.default_rng(seed)
     for c in range(6):
         assert fuzz_sharded.run_case(100 * seed + c, rng)
+
+
+@pytest.mark.parametrize("seed", [31])
+def test_random_large_indexes_with_the_seed_model(pn, oracle_mod, seed):
+    """tests/fuzz_seed_model.py: 10^5 .. 6 10^5 rows (where the seed model is fitted), ten data families, four kinds of
+    queries, f32 / f64, Euclidean / Cosine: the bf16 tier with the model on and off == the exact engine == the oracle."""
+    import fuzz_seed_model
+    rng = np.random.default_rng(seed)
+    for c in range(5):
+        assert fuzz_seed_model.run_case(100 * seed + c, rng)
