@@ -714,8 +714,7 @@ def main():
         elif args.engine != "exact" and tree is not None and tree.mfma_eligible:
             engine_used, peak = "mfma", PEAK_F32_MFMA_TFLOPS
             kernel_name = ("mfma_filter_wide_kernel" if dim > 128 else
-                           "mfma_filter_v2_kernel" if (args.structure != 1 and k + 2 + k // 16 <= 224 and args.slots <= 224)
-                           else "mfma_filter_kernel")
+                           "mfma_filter_v2_kernel")
         else:
             engine_used, kernel_name, peak = "exact", "exact_knn_kernel", PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of this same

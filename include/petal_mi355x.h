@@ -84,8 +84,9 @@ enum {
     PN_OPT_PROFILE = 4,     /* 1: bracket the dominant kernel with hipEvents on its stream (hot_ms); 2: also the whole
                                call (last_call_ms) -- every event record costs the stream a few microseconds */
     PN_OPT_FILTER_SLOTS = 5, /* k' kept by the MFMA filter per (query, segment); 0 = auto */
-    PN_OPT_MFMA_STRUCTURE = 6, /* 0 auto; 1 = (query tile x segment) grid; 2 = persistent partition, LDS candidate
-                                 buffers, 1 workgroup/CU; 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU */
+    PN_OPT_MFMA_STRUCTURE = 6, /* f32 MFMA tier: 0 auto; 2 = persistent partition, LDS candidate buffers, 1 workgroup/CU;
+                                 3 = persistent partition, HBM candidate buffers, 2 workgroups/CU (1, the first
+                                 structure -- a (query tile x segment) grid -- was retired in round 4: PN_ERR_INVALID) */
     PN_OPT_EXCHANGE_ALWAYS = 7, /* pn_sharded_set_option only.  A handle with ONE shard answers straight into the
                                   caller's buffers (nothing to exchange); 1 sends it through the packed buffer, the
                                   all-gather and the merge all the same (tests: RCCL at world size 1) */

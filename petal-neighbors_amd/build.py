@@ -36,7 +36,6 @@ UNITS = [
     ("exact_scan.hip", ["-ffp-contract=off"]),
     ("select.hip", ["-ffp-contract=off"]),
     ("pack.hip", []),
-    ("mfma_filter.hip", []),
     ("mfma_filter_v2.hip", []),
     ("bf16_filter.hip", []),
     ("sharded.hip", []),

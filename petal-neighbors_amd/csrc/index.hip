@@ -218,7 +218,7 @@ struct pn_index {
     uint64_t index_base = 0;
     int profile = 0;
     int filter_slots = 0;
-    int mfma_structure = 0;  // 0 auto, 1 = grid of (query tile x segment), 2 = persistent balanced partition
+    int mfma_structure = 0;  // 0 auto, 2 = persistent partition with LDS buffers, 3 = with HBM buffers (1: retired)
     int shared_tau = 1;      // PN_OPT_SHARED_THRESHOLDS: 0 off, 1 auto, >= 2 the rank itself
     int bf16_waves = 0;      // PN_OPT_BF16_WAVES: 0 auto (8-wave main-pass kernel where it applies), 4 = 4-wave kernel
     // Seed model (round 4, seed_model_build): starting thresholds of a k-NN call from per-dimension moments of the corpus,
@@ -323,7 +323,7 @@ static size_t pick_ld(size_t dim) {
 }
 
 static float mfma_alpha(size_t dim) {
-    // (2(D+2)+8) * 2^-24: covers the (D+2)-step MFMA fma chain twice (see mfma_filter.hip)
+    // (2(D+2)+8) * 2^-24: covers the (D+2)-step MFMA fma chain twice (see mfma_filter_v2.hip)
     return (float)((2.0 * (double)(dim + 2) + 8.0) * 5.9604644775390625e-08);
 }
 
@@ -937,6 +937,7 @@ extern "C" int pn_index_set_option(pn_index *ix, int option, int64_t value) {
             ix->filter_slots = (int)value;
             return PN_OK;
         case PN_OPT_MFMA_STRUCTURE:
+            if (value == 1) return fail(PN_ERR_INVALID, "structure 1 (the (query tile x segment) grid) was retired in round 4");
             if (value < 0 || value > 3) return fail(PN_ERR_INVALID, "bad structure");
             ix->mfma_structure = (int)value;
             return PN_OK;
@@ -1229,7 +1230,7 @@ static int second_tier_exact(const pn_index *ix, Workspace &ws, const T *Qp, siz
 static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
     if (ix->filter_slots > 0) return (size_t)ix->filter_slots < kout ? kout : (size_t)ix->filter_slots;
     const size_t q_tiles = nq_pad / 128;
-    const bool many_segments = ix->mfma_structure != 1 && q_tiles * 3 <= (size_t)ix->n_cu;  // >= 3 segments per query tile
+    const bool many_segments = q_tiles * 3 <= (size_t)ix->n_cu;  // >= 3 segments per query tile
     if (many_segments && kout + 2 + kout / 16 <= 224) return kout + 2 + kout / 16;
     return kout + (kout < 16 ? 6 : kout / 4 + 4);
 }
@@ -1776,20 +1777,20 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
     // persistent-partition kernels: k' <= 30 with LDS candidate buffers (structure 2, wide rows), k' <= 224 with
     // HBM candidate buffers and two workgroups per CU (structure 3, the default for D <= 128)
     const bool hbm_ok = (ix->mfma_structure == 0 || ix->mfma_structure == 3);
-    const bool v2 = ix->mfma_structure != 1 && (kp <= 30 || (hbm_ok && ix->ld <= 128 && kp <= 224));
-    if (!v2 && ix->ld > 128) return fail(PN_ERR_UNSUPPORTED, "wide rows need k' <= 30 on the MFMA path");
-    int cap = v2 ? (int)round_up(kp, 32) : pick_cap(kp);
-    if (!cap) return fail(PN_ERR_UNSUPPORTED, "filter slots %zu too large", kp);
+    const bool v2 = kp <= 30 || (hbm_ok && ix->ld <= 128 && kp <= 224);
+    if (!v2) return fail(PN_ERR_UNSUPPORTED, ix->ld > 128 ? "wide rows need k' <= 30 on the MFMA path"
+                                                            : "k' = %zu is beyond the MFMA path's buffers", kp);
+    const int cap = (int)round_up(kp, 32);
     // scaled query norms (same kernel as the corpus norms)
     PNCHK(ws.w_qnorm.ensure(nq_pad * sizeof(float)));
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [0] flagged count, [1] non-finite query norms, [4] second-tier list length
     HIPCHK(launch_row_norms_f32(Qp, nq_pad, nq, (int)ix->dim, ix->ld, mfma_alpha(ix->dim), (float *)ws.w_qnorm.p,
                                 d_misc + 1, s));
-    MfmaPlan plan{};
     // structure 3: persistent partition with HBM candidate buffers and two workgroups per CU
-    const bool two_per_cu = v2 && hbm_ok;
+    const bool two_per_cu = hbm_ok;
     int n_wg = two_per_cu ? 2 * ix->n_cu : ix->n_cu;
-    if (v2) {
+    struct { int nseg; } plan{};
+    {
         // at most ~32 workgroups per query tile and at least ~32 row tiles per workgroup
         const size_t q_tiles = nq_pad / 128, r_tiles = (ix->n + 63) / 64;
         size_t cap_wg = q_tiles * 32;
@@ -1798,12 +1799,6 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
         if (cap_wg < 1) cap_wg = 1;
         if ((size_t)n_wg > cap_wg) n_wg = (int)cap_wg;
         plan.nseg = mfma_v2_max_segments(nq_pad / 128, n_wg);
-        plan.seg_len = 0;
-        plan.kp = (int)kp;
-        plan.cap = cap;
-    } else {
-        const ScanPlan sp = plan_segments(ix->n, nq_pad / 128, cap, ix->opt_segments, 16384, 8192, 512, true);
-        plan = MfmaPlan{sp.nseg, sp.seg_len, (int)kp, cap};
     }
     const size_t cells = (size_t)plan.nseg * nq_pad;
     const size_t slots = cells * (size_t)cap;
@@ -1814,10 +1809,9 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
     PNCHK(ws.w_flags.ensure(nq_pad * sizeof(uint32_t)));
     PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));  // the re-rank lists the queries it could not prove here
     CandBuf cb{ws.w_keys.p, (uint32_t *)ws.w_idx.p, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, plan.nseg, cap};
-    if (v2) {  // not every (segment, query tile) cell is written by the persistent partition
-        HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_tau.p, (int)0xFF800000u, cells, s));
-    }
+    // not every (segment, query tile) cell is written by the persistent partition
+    HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ws.w_tau.p, (int)0xFF800000u, cells, s));
     const bool prof = rec && rec->prof;
     if (prof) {
         HIPCHK(hipEventRecord(rec->ev[0], s));
@@ -1828,12 +1822,8 @@ static int run_mfma(const pn_index *ix, Workspace &ws, const float *Qp, size_t n
         PNCHK(ws.w_sel.ensure(mfma_v2_gcand_bytes(n_wg, (int)kp)));
         gcand = (uint32_t *)ws.w_sel.p;
     }
-    if (v2)
-        HIPCHK(launch_mfma_filter_v2_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp,
-                                         (const float *)ws.w_qnorm.p, ix->ld, (int)kp, cb, n_wg, gcand, s));
-    else
-        HIPCHK(launch_mfma_filter_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->n_pad, (int)ix->dim, ix->ld,
-                                      Qp, (const float *)ws.w_qnorm.p, (int)nq, ix->ld, plan, cb, s));
+    HIPCHK(launch_mfma_filter_v2_f32((const float *)ix->d_pts, ix->d_norm, ix->n, ix->ld, Qp, (const float *)ws.w_qnorm.p,
+                                     ix->ld, (int)kp, cb, n_wg, gcand, s));
     if (prof) HIPCHK(hipEventRecord(rec->ev[1], s));
     HIPCHK(launch_select_rerank_f32(cb, (const float *)ix->d_pts, ix->n, (int)ix->dim, ix->ld, Qp, (int)nq, ix->ld,
                                     (int)kout, ix->index_base, d_idx, d_dist, out_stride, (uint32_t *)ws.w_flags.p,

@@ -1,13 +1,28 @@
 // mfma_filter_v2.hip -- second tier of the k-NN path (and the radius filter of the f32 tier): proven lower
 // bounds of |q-p|^2 on the f32 matrix cores, persistent-partition structures.
 //
-// Same mathematics as mfma_filter.hip (read its header first: L(q,p) is a proven lower bound of |q-p|^2
-// computed as one (D+2)-step fma chain on v_mfma_f32_32x32x2_f32, query on the lane, 16 rows in registers).
-// What this file changes is how the chip is kept busy; every item below was measured (profiles/r01_*):
+// WHAT IS COMPUTED.  For every (query q, corpus row p) one f32 value
+//       L(q,p) = qn'(q) + pn'(p) + sum_k (-2 q_k) * p_k
+// as ONE chain of D+2 fused multiply-adds on v_mfma_f32_32x32x2_f32 (exact f32, bit-for-bit an fmaf chain, no flush of
+// subnormals), query on the lane, 16 rows in registers.  qn', pn' are the squared norms accumulated in f64 and rounded
+// DOWN after scaling by (1 - alpha), alpha = (2(D+2)+8) * 2^-24, minus 1e-36 (pack.hip: row_norms).
+//
+// WHY IT IS A LOWER BOUND.  Standard fma-chain analysis: the computed chain differs from the exact sum of its D+2 terms
+// t_j by at most gamma_{D+2} * sum|t_j| (+ (D+2) * 2^-149 for gradual underflow), and
+// sum|t_j| = qn' + pn' + 2 sum|q_k p_k| <= qn' + pn' + (|q|^2 + |p|^2).  With qn' <= |q|^2 (1 - alpha), pn' likewise:
+//       L <= (|q|^2+|p|^2)[(1-alpha)(1+gamma) + gamma] - 2 q.p  <=  |q-p|^2
+// because alpha >= 2 gamma_{D+2} / (1 + gamma_{D+2}).  So L <= d2(q,p) in REAL arithmetic for every pair; the order in
+// which k is summed is irrelevant to the bound, which lets the kernel feed the MFMA 8 coordinates per 16-B LDS read.
+// select.hip turns "L >= tau for every dropped row" into a proof that the exact top-k is among the candidates, or flags
+// the query for the exact engine.  Rows / queries beyond the real counts carry norm +inf: L = +inf.
+// (Round 1's first structure -- a static (query tile x segment) grid, mfma_filter.hip -- computed the same bound; it
+// was retired in round 4 once nothing but PN_OPT_MFMA_STRUCTURE = 1 selected it.)
+//
+// How the chip is kept busy; every item below was measured (profiles/r01_*):
 //
 //  * BALANCED PERSISTENT PARTITION.  The work is the list of (query tile, 64-row tile) units in query-major
 //    order; workgroup w of W owns the contiguous slice [w*U/W, (w+1)*U/W).  Every workgroup gets the same number
-//    of MFMAs (+-1 tile) for any Q and N -- the static (query tile x segment) grid of mfma_filter.hip left 6-7 %
+//    of MFMAs (+-1 tile) for any Q and N -- the static (query tile x segment) grid of round 1 left 6-7 %
 //    of the workgroup slots empty at Q = 10^4.  A slice crosses at most a few query-tile boundaries; at each it
 //    flushes its candidates and reloads the B operand.  "Segment" of a query tile = ordinal of the workgroup
 //    among those that touch it (<= ceil(W/QT)+1 of them).
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void mfma_radius_kernel(
             if (__any(m < tau_excl)) {
                 radius_append(acc0, tau_excl, rt * kV2P, h, rcnt, ridx, cell, cap);
                 radius_append(acc1, tau_excl, rt * kV2P + 32, h, rcnt, ridx, cell, cap);
-                __builtin_amdgcn_s_waitcnt(0x0070);  // drain the list stores (see mfma_filter.hip)
+                __builtin_amdgcn_s_waitcnt(0x0070);  // drain the list stores before the counters
             }
             __syncthreads();
         }
@@ -1004,6 +1019,15 @@ hipError_t launch_mfma_filter_v2_f32(const float *P, const float *pnorm, size_t 
         case 96: return launch_v2_pick<12>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
         case 128: return launch_v2_pick<16>(P, pnorm, n_tiles, Q, qnorm, q_tiles, (uint32_t)kp, cb, n_wg, gcand, s);
         default: return hipErrorInvalidValue;
+    }
+}
+
+// rows the f32 MFMA tier serves: padded row lengths its K loop is instantiated for
+bool mfma_supported(int dim, size_t ld) {
+    if (dim < 1) return false;
+    switch (ld) {
+        case 8: case 16: case 32: case 64: case 96: case 128: return true;
+        default: return ld > 128 && ld % 128 == 0;  // wide rows: the slab-accumulating kernel
     }
 }
 

@@ -225,23 +225,14 @@ hipError_t launch_pack_rows_f32(const float *src, size_t n, size_t cols, size_t 
 hipError_t launch_pack_rows_f64(const double *src, size_t n, size_t cols, size_t row_stride, double *dst,
                                 size_t n_pad, size_t ld, hipStream_t s);
 hipError_t launch_fill_uniform_f32(float *out, uint64_t count, uint64_t seed, uint64_t first, hipStream_t s);
-// scaled squared row norms for the MFMA lower bound (see mfma_filter.hip)
+// scaled squared row norms for the MFMA lower bound (see mfma_filter_v2.hip)
 hipError_t launch_row_norms_f32(const float *X, size_t n_pad, size_t n, int dim, size_t ld, float alpha,
                                 float *norm_out, uint32_t *nonfinite_flag, hipStream_t s);
 
-// ---- mfma_filter.hip
-struct MfmaPlan {
-    int nseg;        // corpus segments per query tile
-    size_t seg_len;  // rows per segment (multiple of the kernel's row tile)
-    int kp;          // candidates kept per (segment, query)
-    int cap;         // slots per (segment, query)
-};
+// ---- mfma_filter_v2.hip (the f32 MFMA tier; round 4: the first structure, a (query tile x segment) grid in
+// mfma_filter.hip, is retired -- nothing selected it but PN_OPT_MFMA_STRUCTURE = 1)
 bool mfma_supported(int dim, size_t ld);
-hipError_t launch_mfma_filter_f32(const float *P, const float *pnorm, size_t n, size_t n_pad, int dim,
-                                  size_t ldp, const float *Q, const float *qnorm, int nq, size_t ldq,
-                                  const MfmaPlan &plan, const CandBuf &cb, hipStream_t s);
-const char *mfma_kernel_name();
-// second structure (mfma_filter_v2.hip): persistent balanced partition, k' <= 32, 32 slots per (segment, query)
+// persistent balanced partition, k' <= 32 with LDS buffers / k' <= 224 with HBM buffers
 int mfma_v2_max_segments(size_t q_tiles, int n_wg);
 // gcand != nullptr: candidate buffers in HBM (mfma_v2_gcand_bytes(n_wg) bytes), 2 workgroups per CU
 size_t mfma_v2_gcand_bytes(int n_wg, int kp);

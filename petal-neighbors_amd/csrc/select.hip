@@ -234,7 +234,7 @@ hipError_t launch_select_exact_f64(const CandBuf &cb, int nq, int kout, uint64_t
 // MFMA mode: exact re-rank + verification.  block = 64 threads = one query.
 //
 // Candidates: per segment up to `cap` (idx, L) pairs with L <= d2(q, p) in real
-// arithmetic for every corpus row p (mfma_filter.hip proves this bound), and
+// arithmetic for every corpus row p (mfma_filter_v2.hip proves this bound), and
 // tau_seg such that every row of the segment NOT in the buffer has L >= tau_seg
 // (tau_seg = +inf when nothing was ever dropped).
 //

@@ -1,5 +1,5 @@
 // topk_buffer.h -- per-(segment, query) candidate buffers shared by the scan
-// kernels (exact_scan.hip, mfma_filter.hip).
+// kernels (exact_scan.hip, mfma_filter_v2.hip).
 //
 // A buffer lives in HBM: `cap` (key, row) slots, an entry count and a running
 // threshold tau.  A value enters when key < tau.  The wave that owns the query

@@ -276,7 +276,7 @@ def test_mfma_engine_falls_back_on_unprovable_queries(pn, oracle_mod):
     g = np.concatenate([g, g, g])  # every row three times
     qs = np.array([[3, 3, 3, 1], [0.5, 0.5, 0.5, 0.5], [15, 15, 15, 3], [7.25, 3, 1, 2]], dtype=np.float32)
     from petal_neighbors_amd import _lib
-    tree = _check_knn(pn, oracle_mod, g, qs, 10, "mfma", {_lib.PN_OPT_MFMA_STRUCTURE: 1, _lib.PN_OPT_SEGMENTS: 1})
+    tree = _check_knn(pn, oracle_mod, g, qs, 10, "mfma", {_lib.PN_OPT_MFMA_STRUCTURE: 2, _lib.PN_OPT_FILTER_SLOTS: 10})
     assert tree.stats()["fallback_queries"] >= 1
     _check_knn(pn, oracle_mod, g, qs, 10, "mfma")
     same = np.full((6000, 32), 0.25, dtype=np.float32)
@@ -311,7 +311,7 @@ def test_mfma_filter_slot_count_does_not_change_results(pn, oracle_mod, slots):
     _check_knn(pn, oracle_mod, pts, qs, 10, "mfma", {_lib.PN_OPT_FILTER_SLOTS: slots, _lib.PN_OPT_SEGMENTS: 3})
 
 
-@pytest.mark.parametrize("structure", [1, 2, 3])
+@pytest.mark.parametrize("structure", [2, 3])
 @pytest.mark.parametrize("n,dim,nq,k", [(40000, 128, 300, 10), (9000, 96, 130, 20), (2000, 16, 700, 3), (300, 8, 5, 1)])
 def test_mfma_both_kernel_structures(pn, oracle_mod, structure, n, dim, nq, k):
     """structure 1 = (query tile x segment) grid; 2 / 3 = persistent balanced partition with LDS / HBM
