@@ -760,6 +760,7 @@ def main():
                          **(lambda ks: ({"kernel_ms_main": ks[0]["main_ms"], "kernel_ms_scout": ks[0]["scout_ms"],
                                          "kernel_split_source": f"{ks[1]} (rocprofv3 --kernel-trace --stats of this command; "
                                                                 f"main + scout = {ks[0]['main_ms'] + ks[0]['scout_ms']:.4f} ms)"}
+                                        | ({"kernel_split_note": ks[0]["note"]} if "note" in ks[0] else {})
                                         if ks else {}))(committed_kernel_split(args.config) if world == 1 and args.mode == "knn" else None),
                          **({"traffic_kernel_ms_under_pmc": traffic_ms} if traffic_ms else {}),
                          "whole_step_frac": round(2.0 * n * dim * nq / (ms_per_step * 1e-3) / 1e12
