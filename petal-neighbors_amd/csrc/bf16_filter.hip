@@ -754,6 +754,42 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
                 *reinterpret_cast<tp_ *>(qd + i) = pr;
             }
     }
+    // the translation vector and the seed model's words of this lane's columns: 16-byte loads where the columns allow
+    // it (hipMalloc'ed arrays, c0 a multiple of four)
+    float muv[18], m1v[18], av[18], bv[18];
+    const bool vecm = (CH % 4) == 0 && c0 + CH <= dim;
+#pragma unroll
+    for (int i = 0; i < 18; i += 4) {
+        if (i + 4 <= CH && vecm) {
+            typedef float f4_ __attribute__((ext_vector_type(4)));
+            const f4_ t4 = *reinterpret_cast<const f4_ *>(mu + c0 + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) muv[i + j] = t4[j];
+            if (sm.seed_out) {
+                const f4_ x4 = *reinterpret_cast<const f4_ *>(sm.m1 + c0 + i);
+                const f4_ y4 = *reinterpret_cast<const f4_ *>(sm.a + c0 + i);
+                const f4_ z4 = *reinterpret_cast<const f4_ *>(sm.b + c0 + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m1v[i + j] = x4[j];
+                    av[i + j] = y4[j];
+                    bv[i + j] = z4[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = c0 + i + j;
+                const bool in = i + j < 18 && i + j < CH && k < dim;
+                if (i + j < 18) {
+                    muv[i + j] = in ? mu[k] : 0.0f;
+                    m1v[i + j] = in && sm.seed_out ? sm.m1[k] : 0.0f;
+                    av[i + j] = in && sm.seed_out ? sm.a[k] : 0.0f;
+                    bv[i + j] = in && sm.seed_out ? sm.b[k] : 0.0f;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         v[i] = 0;
@@ -761,7 +797,7 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
         if (i < CH && k < dim && q < nq) {
             const double x = (double)xf[i];
             finite = finite && (fabs(x) < 1.0e30);
-            const double c = x - (double)mu[k];
+            const double c = x - (double)muv[i];
             const float cf = (float)c;
             const uint16_t hb = (fabsf(cf) < 8.67361737988403547e-19f) ? (uint16_t)0 : bf_rne(cf);
             const float xh = bf_f(hb);
@@ -771,8 +807,8 @@ __global__ void bf16_pack_queries8_kernel(const T *__restrict__ Q, const float *
             en += e * e;
             hn += (double)xh * (double)xh;
             if (sm.seed_out) {  // seed model: this coordinate's share of the bound's mean and variance over the corpus
-                sm_mean += c * (double)sm.m1[k];
-                sm_var += c * (c * (double)sm.a[k] - (double)sm.b[k]);
+                sm_mean += c * (double)m1v[i];
+                sm_var += c * (c * (double)av[i] - (double)bv[i]);
             }
         }
     }
@@ -1411,7 +1447,8 @@ __device__ __forceinline__ void bf_slow(const f32x16 &acc, float mn, float &tau,
     // entries per tile and wave; measured alternative to that: all compares first, then a scalar loop over the
     // registers with survivors and a switch to read them, 1320 cycles.)
 #ifndef PN_DIAG_BF_SLOW_LOOP
-    unsigned long long seen = 0ull, dup = 0ull;
+    unsigned long long seen = 0ull, dup = 0ull;  // (seen: only the counting builds read it)
+    (void)seen;
     uint32_t ridx = 16u;
     if (TAGGED) {
         // The narrow kernel's main loop wrote every bound's register number into its low four mantissa bits while
