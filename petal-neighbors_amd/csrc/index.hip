@@ -134,7 +134,7 @@ struct DevBuf {
 // buffers (same stream: stream order is enough).
 struct Workspace {
     DevBuf w_q, w_qnorm, w_qnrm, w_keys, w_idx, w_cnt, w_tau, w_flags, w_sel, w_misc, w2_keys, w2_idx, w2_cnt, w2_tau, w_lo;
-    DevBuf w_bq, w_qn, w_qbad, w_gq, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
+    DevBuf w_bq, w_qn, w_qbad, w_gq, w_gqn, w_gidx, w_gdist, w_gsel, w_seed, w_qstat, w_lists;  // bf16 tier, second tier
     DevBuf w_hq, w_hidx, w_hdist;  // staging of the host entry points (queries up, results down)
     DevBuf w_fparts;               // second tier, many-segment path: per-group partial results
     DevBuf w_rpos, w_rfin, w_rcx, w_rox, w_rscan;  // pn_query_radius_device_*: list positions, counts, per-segment counts / offsets, scan scratch
@@ -163,7 +163,7 @@ struct Workspace {
     hipEvent_t done = nullptr;
     hipStream_t last_stream = nullptr;
     bool in_flight = false;
-    DevBuf *all[35] = {&w_rpos, &w_rfin, &w_rcx, &w_rox, &w_rscan, &w_q, &w_qnorm, &w_qnrm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
+    DevBuf *all[36] = {&w_gqn, &w_rpos, &w_rfin, &w_rcx, &w_rox, &w_rscan, &w_q, &w_qnorm, &w_qnrm, &w_keys, &w_idx, &w_cnt, &w_tau, &w_flags, &w_sel, &w_misc, &w2_keys, &w2_idx,
                        &w2_cnt, &w2_tau, &w_lo, &w_bq, &w_qn, &w_qbad, &w_gq, &w_gidx, &w_gdist, &w_gsel, &w_seed,
                        &w_qstat, &w_lists, &w_hq, &w_hidx, &w_hdist, &w_fparts, &w_pcnt};
     std::vector<void *> retired;  // outgrown allocations, freed once `done` has passed (DevBuf::ensure)
@@ -2485,7 +2485,7 @@ static int radius_exact(const pn_index *ix, Workspace &ws, const T *Qp, size_t n
 template <typename T>
 static int radius_finish(const pn_index *ix, Workspace &ws, const T *Qp, size_t nq, size_t kept_stride, uint32_t *d_misc,
                          const uint32_t *d_over, T radius, uint64_t *offsets, uint64_t **idx_out, bool *done,
-                         hipStream_t s) {
+                         hipStream_t s, bool cosine = false) {
     uint32_t h_misc[2] = {0, 0};
     std::vector<uint32_t> h_n(nq);
     HIPCHK(hipMemcpyAsync(h_misc, d_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
@@ -2550,8 +2550,15 @@ static int radius_finish(const pn_index *ix, Workspace &ws, const T *Qp, size_t 
                                   (uint32_t)nf, (T *)ws.w_gq.p, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)  // `sel` is pageable host memory: the copy must have left it
             rc = fail(PN_ERR_DEVICE, "radius fallback staging failed: %s", hipGetErrorString(hipGetLastError()));
+        const T *gqnorm = nullptr;
+        if (rc == PN_OK && cosine) {  // a Cosine index: the gathered queries' norms (their rows are dim long: over the row)
+            if (ws.w_gqn.ensure(nf_pad * sizeof(T)) != PN_OK || hipMemsetAsync(ws.w_gqn.p, 0, nf_pad * sizeof(T), s) != hipSuccess ||
+                Ops<T>::cnorms((const T *)ws.w_gq.p, nf, (int)ix->dim, ix->ld, (T *)ws.w_gqn.p, s) != hipSuccess)
+                rc = fail(PN_ERR_DEVICE, "radius fallback query norms failed");
+            gqnorm = (const T *)ws.w_gqn.p;
+        }
         if (rc == PN_OK)
-            rc = radius_exact<T>(ix, ws, (const T *)ws.w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s);
+            rc = radius_exact<T>(ix, ws, (const T *)ws.w_gq.p, nf, nf_pad, ix->dim, radius, offs_x, &out_x, s, gqnorm);
         if (rc != PN_OK) {
             free(h_out);
             return rc;
@@ -2604,8 +2611,10 @@ static int radius_finish(const pn_index *ix, Workspace &ws, const T *Qp, size_t 
 // queries the filter cannot serve, d_misc[0] / [1] = how many of either.  *enq = false: the radius cannot be served.)
 template <typename T>
 static int radius_bf16_enqueue(const pn_index *ix, Workspace &ws, int level, const T *Qp, size_t nq, size_t nq_pad, T radius,
-                               size_t *kept_stride_out, bool *enq, hipStream_t s) {
+                               size_t *kept_stride_out, bool *enq, hipStream_t s, const T *qnorm = nullptr) {
     *enq = false;
+    const bool cosine = ix->metric == 1;  // (round 4: the filter over the normalised rows, Cosine::distance check)
+    if (cosine && (!qnorm || !ix->d_cnorm || !(radius < (T)1))) return PN_OK;  // (r >= 1: half the sphere -- exact scan)
     const int cap = 256;  // up to 224 rows within the radius per (segment, query) before the call overflows
     const size_t q_tiles = nq_pad / 256, r_tiles = (ix->n + 63) / 64;
     size_t n_wg = (size_t)ix->n_cu * 2;
@@ -2626,7 +2635,13 @@ static int radius_bf16_enqueue(const pn_index *ix, Workspace &ws, int level, con
     const size_t kept_stride = (size_t)nseg * cap;
     // tau_r = (r^2 + 1e-37) / (1 - (D+4) 2^-24): every row whose reference distance is < r has a squared distance
     // below it (same allowances as the k-NN proof)
-    const double t = sizeof(T) == 4
+    // Cosine: a row whose reference distance is < r has |q~ - p~|^2 < 2 (r + E' + 1e-14) + eps1 -- cos_proof_lb
+    // (select.hip) read backwards, with its (|x| + 1) 1e-15 term bounded for |x| <= 9
+    const double ut = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+    const double t = cosine
+                         ? 2.0 * ((double)radius + (2.0 * (double)ix->dim + 16.0) * ut + 1.0e-14) +
+                               (4.5 * (double)ix->dim + 45.0) * 1.1102230246251565e-16
+                     : sizeof(T) == 4
                          ? ((double)radius * (double)radius + 1e-37) / (1.0 - (double)(ix->dim + 4) * 5.9604644775390625e-08)
                          : ((double)radius * (double)radius * (1.0 + 8.881784197001252e-16) + 1e-300) /
                                (1.0 - (double)(ix->dim + 4) * 1.1102230246251565e-16);  // (f64: r^2 itself is rounded)
@@ -2645,8 +2660,16 @@ static int radius_bf16_enqueue(const pn_index *ix, Workspace &ws, int level, con
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [0] overflow count, [1] queries the filter cannot serve
     HIPCHK(hipMemsetAsync(ws.w_misc.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ws.w_cnt.p, 0, cells * sizeof(uint32_t), s));
-    HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
-                                    (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
+    if (cosine) {  // q~ = q / |q| in f64 (a query without a direction becomes NaNs: flagged by the pack kernel, exact scan)
+        PNCHK(ws.w_qnrm.ensure(nq_pad * ix->ld * sizeof(double)));
+        HIPCHK(launch_cos_normalize_rows<T>(Qp, nq, nq_pad, (int)ix->dim, ix->ld, (double *)ws.w_qnrm.p, ix->ld, nullptr,
+                                            true, s));
+        HIPCHK(launch_bf16_pack_queries<double>((const double *)ws.w_qnrm.p, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld,
+                                                ws.w_bq.p, (double *)ws.w_qn.p, (uint32_t *)ws.w_qbad.p, ix->bf16_ci,
+                                                ix->bf16_bmax, ix->bf16_dmax, s));
+    } else
+        HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
+                                        (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
     PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
     HIPCHK(launch_compact_flags((const uint32_t *)ws.w_qbad.p, (int)nq, (uint32_t *)ws.w_gsel.p, d_misc + 1, s));
     HIPCHK(launch_bf16_radius_tau((const double *)ws.w_qn.p, nq_pad, t, (uint32_t *)ws.w_seed.p, s));
@@ -2671,23 +2694,24 @@ static int radius_bf16_enqueue(const pn_index *ix, Workspace &ws, int level, con
     HIPCHK(launch_radius_check<T>((const uint32_t *)ws.w_cnt.p, (const uint32_t *)ws.w_idx.p + 1, nq_pad, nseg, cap,
                                   (const T *)ix->d_pts, ix->ld, Qp, (int)nq, (int)ix->dim, radius,
                                   (uint32_t *)ws.w_keys.p, (uint32_t *)ws.w_flags.p, d_misc, 2,
-                                  (uint32_t *)ws.w_sel.p, s));
+                                  (uint32_t *)ws.w_sel.p, s, cosine ? (const T *)ix->d_cnorm : nullptr,
+                                  cosine ? qnorm : nullptr));
     *kept_stride_out = kept_stride;
     *enq = true;
     return PN_OK;
 }
 template <typename T>
 static int radius_bf16(const pn_index *ix, Workspace &ws, int level, const T *Qp, size_t nq, size_t nq_pad, T radius, uint64_t *offsets,
-                       uint64_t **idx_out, bool *done, hipStream_t s) {
+                       uint64_t **idx_out, bool *done, hipStream_t s, const T *qnorm = nullptr) {
     *done = false;
     size_t kept_stride = 0;
     bool enq = false;
-    PNCHK(radius_bf16_enqueue<T>(ix, ws, level, Qp, nq, nq_pad, radius, &kept_stride, &enq, s));
+    PNCHK(radius_bf16_enqueue<T>(ix, ws, level, Qp, nq, nq_pad, radius, &kept_stride, &enq, s, qnorm));
     if (!enq) return PN_OK;
     const bool prof = ix->profile != 0;
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;
     const int rc = radius_finish<T>(ix, ws, Qp, nq, kept_stride, d_misc, (const uint32_t *)ws.w_sel.p, radius, offsets,
-                                    idx_out, done, s);
+                                    idx_out, done, s, ix->metric == 1);
     if (prof && rc == PN_OK) {  // (radius_finish has waited for the stream)
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ws.ev_r[0], ws.ev_r[1]) == hipSuccess) {
@@ -2777,11 +2801,23 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
             break;
         }
         const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-        // (Euclidean indexes; a Cosine index's query_radius stays on the exact two-pass scan)
-        if (ix->metric == 0 && ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
+        const T *qnorm = nullptr;
+        if (ix->metric == 1) {  // Cosine: the queries' norms over their own length
+            rc = ws.w_qnorm.ensure(nq_pad * sizeof(T));
+            if (rc != PN_OK) break;
+            if (hipMemsetAsync(ws.w_qnorm.p, 0, nq_pad * sizeof(T), s) != hipSuccess ||
+                Ops<T>::cnorms((const T *)ws.w_hq.p, nq, (int)q_cols, q_cols ? q_cols : 1, (T *)ws.w_qnorm.p, s) != hipSuccess) {
+                rc = fail(PN_ERR_DEVICE, "query norms failed");
+                break;
+            }
+            qnorm = (const T *)ws.w_qnorm.p;
+        }
+        // (Euclidean indexes, and -- round 4 -- Cosine indexes for queries as long as the rows and r < 1: the filter over the
+        // normalised rows + the Cosine::distance check of its survivors; everything else: the exact two-pass scan)
+        if ((ix->metric == 0 || q_cols == ix->dim) && ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
             (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8))) {
             bool done = false;  // (f32 and f64 indexes)
-            rc = radius_bf16<T>(ix, ws, level, (const T *)Qp, nq, nq_pad, radius, offsets, idx_out, &done, s);
+            rc = radius_bf16<T>(ix, ws, level, (const T *)Qp, nq, nq_pad, radius, offsets, idx_out, &done, s, qnorm);
             if (rc != PN_OK || done) break;
         }
         if constexpr (sizeof(T) == 4) {
@@ -2793,17 +2829,6 @@ static int radius_host_impl(const pn_index *ix, const T *q, size_t nq, size_t q_
                 std::lock_guard<std::mutex> lk(ix->sh.mu);
                 ix->sh.stats.fallback_queries += nq;  // survivor list overflow / non-finite query: exact engine
             }
-        }
-        const T *qnorm = nullptr;
-        if (ix->metric == 1) {  // Cosine: the queries' norms over their own length
-            rc = ws.w_qnorm.ensure(nq_pad * sizeof(T));
-            if (rc != PN_OK) break;
-            if (hipMemsetAsync(ws.w_qnorm.p, 0, nq_pad * sizeof(T), s) != hipSuccess ||
-                Ops<T>::cnorms((const T *)ws.w_hq.p, nq, (int)q_cols, q_cols ? q_cols : 1, (T *)ws.w_qnorm.p, s) != hipSuccess) {
-                rc = fail(PN_ERR_DEVICE, "query norms failed");
-                break;
-            }
-            qnorm = (const T *)ws.w_qnorm.p;
         }
         std::vector<uint64_t> offs;
         rc = radius_exact<T>(ix, ws, Qp, nq, nq_pad, dim_eff, radius, offs, idx_out, s, qnorm);
@@ -2832,7 +2857,8 @@ extern "C" int pn_query_radius_f64(const pn_index *ix, const double *q, size_t n
 //   Euclidean indexes with a bf16 tier: the filter against each query's fixed bound + the exact check of the survivors
 //   (as the host entry point); the queries it cannot serve (survivor list overflow, non-finite norms) are LISTED on the
 //   device and answered by the exact two-pass scan through that list -- counts, offsets and fill all device-driven.
-//   Every other index (Cosine, f64 without a tier, small corpora): the exact two-pass scan for all queries.
+//   Cosine indexes with a bf16 tier, queries as long as the rows, r < 1: the same over the normalised rows, the survivors
+//   checked with Cosine::distance.  Every other case (small corpora, no tier): the exact two-pass scan for all queries.
 // ---------------------------------------------------------------------------
 template <typename T>
 static int radius_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_t q_cols, size_t q_stride, T radius,
@@ -2876,9 +2902,9 @@ static int radius_device_impl(const pn_index *ix, const T *d_q, size_t nq, size_
     bool filtered = false;
     size_t kept_stride = 0;
     const bool finite_pos = radius > (T)0 && radius < (T)INFINITY;
-    if (ix->metric == 0 && ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
+    if ((ix->metric == 0 || q_cols == ix->dim) && ix->bf16_ok && dim_eff == ix->dim && finite_pos && level < 2 &&
         (ix->engine == PN_ENGINE_BF16 || (ix->engine == PN_ENGINE_AUTO && ix->n >= 4096 && ix->dim >= 8)))
-        PNCHK(radius_bf16_enqueue<T>(ix, ws, level, (const T *)Qp, nq, nq_pad, radius, &kept_stride, &filtered, s));
+        PNCHK(radius_bf16_enqueue<T>(ix, ws, level, (const T *)Qp, nq, nq_pad, radius, &kept_stride, &filtered, s, qnorm));
     PNCHK(ws.w_misc.ensure(64));
     uint32_t *d_misc = (uint32_t *)ws.w_misc.p;  // [4]: the number of listed queries
     const uint32_t *d_sel = nullptr, *d_pos = nullptr, *d_nsel = nullptr, *d_nkept = nullptr;

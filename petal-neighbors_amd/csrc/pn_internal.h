@@ -210,7 +210,8 @@ hipError_t launch_gather_rows(const T *src, size_t ld, const uint32_t *sel, cons
 template <typename T>
 hipError_t launch_radius_check(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                const T *P, size_t ldp, const T *Q, int nq, int dim, T r, uint32_t *kept,
-                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s);
+                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s,
+                               const T *cnorm = nullptr, const T *qnorm = nullptr);  // (both: Cosine::distance < r)
 hipError_t launch_gather_rows_f32(const float *src, size_t ld, const uint32_t *sel, const uint32_t *nsel, uint32_t off,
                                   uint32_t max_rows, float *dst, hipStream_t s);
 hipError_t launch_scatter_results_f32(const uint64_t *idx_in, const float *dist_in, const uint32_t *sel,

@@ -989,14 +989,18 @@ hipError_t launch_tiny_query_f64(const double *P, size_t n, int dim_eff, size_t 
 // ---------------------------------------------------------------------------
 // radius: exact check of the filter's survivors.  block = 64 threads = one query.
 // ---------------------------------------------------------------------------
-template <typename T>
+// COS (round 4: query_radius on a Cosine index behind the bf16 filter): the survivors are tested with Cosine::distance in
+// the reference's arithmetic (exact_cosine_prefetched; cnorm = the rows' norms, qnorm = the queries'; len = the padded
+// row length, zeros beyond dim add nothing)
+template <typename T, bool COS>
 __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__restrict__ rcnt,
                                                           const uint32_t *__restrict__ ridx, size_t nq_pad, int nseg,
                                                           uint32_t cap, const T *__restrict__ P, size_t ldp,
                                                           const T *__restrict__ Q, int dim, T r,
                                                           uint32_t *__restrict__ kept, uint32_t *__restrict__ nkept,
                                                           uint32_t *__restrict__ overflow, int ridx_stride,
-                                                          uint32_t *__restrict__ over_q) {
+                                                          uint32_t *__restrict__ over_q, const T *__restrict__ cnorm,
+                                                          const T *__restrict__ qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *srow = reinterpret_cast<uint32_t *>(smem);  // rows that pass the exact test
     __shared__ uint32_t n_pass;
@@ -1012,7 +1016,9 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
         const size_t base = ((size_t)s * nq_pad + q) * (size_t)cap;
         for (uint32_t e = lane; e < c; e += 64) {
             const uint32_t row = ridx[(base + e) * (size_t)ridx_stride];
-            const T d = exact_distance_seq<T>(qrow, P + (size_t)row * ldp, dim);
+            T d;
+            if constexpr (COS) d = exact_cosine_prefetched<T>(qrow, P + (size_t)row * ldp, (int)ldp, qnorm[q], cnorm[row]);
+            else d = exact_distance_seq<T>(qrow, P + (size_t)row * ldp, dim);
             if (d < r) srow[atomicAdd(&n_pass, 1u)] = row;  // strict '<' (src/ball_tree.rs:277); NaN never matches
         }
     }
@@ -1035,25 +1041,32 @@ __global__ __launch_bounds__(64) void radius_check_kernel(const uint32_t *__rest
 template <typename T>
 hipError_t launch_radius_check(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                const T *P, size_t ldp, const T *Q, int nq, int dim, T r, uint32_t *kept,
-                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s) {
+                               uint32_t *nkept, uint32_t *overflow, int ridx_stride, uint32_t *over_q, hipStream_t s,
+                               const T *cnorm, const T *qnorm) {
     const size_t sh = (size_t)nseg * cap * sizeof(uint32_t);
     if (sh > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(radius_check_kernel<T>, dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P, ldp,
-                       Q, dim, r, kept, nkept, overflow, ridx_stride, over_q);
+    if (cnorm || qnorm) {
+        if (!cnorm || !qnorm || ldp % 8) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((radius_check_kernel<T, true>), dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap,
+                           P, ldp, Q, dim, r, kept, nkept, overflow, ridx_stride, over_q, cnorm, qnorm);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((radius_check_kernel<T, false>), dim3((unsigned)nq), dim3(64), sh, s, rcnt, ridx, nq_pad, nseg, cap, P,
+                       ldp, Q, dim, r, kept, nkept, overflow, ridx_stride, over_q, (const T *)nullptr, (const T *)nullptr);
     return hipGetLastError();
 }
 template hipError_t launch_radius_check<float>(const uint32_t *, const uint32_t *, size_t, int, uint32_t, const float *, size_t,
                                                const float *, int, int, float, uint32_t *, uint32_t *, uint32_t *, int,
-                                               uint32_t *, hipStream_t);
+                                               uint32_t *, hipStream_t, const float *, const float *);
 template hipError_t launch_radius_check<double>(const uint32_t *, const uint32_t *, size_t, int, uint32_t, const double *,
                                                 size_t, const double *, int, int, double, uint32_t *, uint32_t *, uint32_t *,
-                                                int, uint32_t *, hipStream_t);
+                                                int, uint32_t *, hipStream_t, const double *, const double *);
 hipError_t launch_radius_check_f32(const uint32_t *rcnt, const uint32_t *ridx, size_t nq_pad, int nseg, uint32_t cap,
                                    const float *P, size_t ldp, const float *Q, int nq, int dim, float r,
                                    uint32_t *kept, uint32_t *nkept, uint32_t *overflow, int ridx_stride,
                                    uint32_t *over_q, hipStream_t s) {
     return launch_radius_check<float>(rcnt, ridx, nq_pad, nseg, cap, P, ldp, Q, nq, dim, r, kept, nkept, overflow,
-                                      ridx_stride, over_q, s);
+                                      ridx_stride, over_q, s, nullptr, nullptr);
 }
 
 __global__ void radius_gather_kernel(const uint32_t *__restrict__ kept, const uint32_t *__restrict__ nkept,

@@ -59,6 +59,25 @@ def run_case(c, rng):
             ei, ed = tc.query_batch(qs, kc)
             nan = np.isnan(ed)
             ok = ok and np.array_equal(np.isnan(cd), nan) and cd[~nan].tobytes() == ed[~nan].tobytes() and np.array_equal(ci[~nan], ei[~nan])
+            # query_radius on the Cosine index (round 4: through the tier for r < 1): a radius exactly at and just above a
+            # stored distance, tier against exact scan, host and device entry
+            fin_d = ed[0][np.isfinite(ed[0])]
+            if len(fin_d):
+                ftc = np.float64 if f64 else np.float32
+                for rc in (ftc(fin_d[-1]), ftc(fin_d[len(fin_d) // 2]) * ftc(1.000001)):
+                    if not (0 < rc < 1):
+                        continue
+                    tc.set_engine("exact")
+                    xo, xi = tc.query_radius_batch(qs, float(rc))
+                    tc.set_engine("auto")
+                    go, gi = tc.query_radius_batch(qs, float(rc))
+                    ok = ok and np.array_equal(go, xo) and np.array_equal(gi, xi)
+                    import torch
+                    qdc = torch.from_numpy(np.ascontiguousarray(qs)).to("cuda:0")
+                    do, di, dt = tc.query_radius_device(qdc, float(rc), int(xo[-1]) + 3)
+                    torch.cuda.synchronize()
+                    ok = ok and int(dt.item()) == int(xo[-1]) and np.array_equal(do.cpu().numpy().astype(np.uint64), xo) and \
+                        np.array_equal(di.cpu().numpy().astype(np.uint64)[: int(xo[-1])], xi)
             if n <= 5000 and nq <= 64:
                 dm = oracle.pairwise_cosine(np.vstack([qs, pts]))[:nq, nq:]
                 for a in range(nq):

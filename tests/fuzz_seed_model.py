@@ -97,6 +97,16 @@ def run_case(c, rng, verbose=True):
     oi, od = t.query_batch(qs, k)
     nan = np.isnan(ed)
     ok = ok and od[~nan].tobytes() == ed[~nan].tobytes() and np.array_equal(oi[~nan], ei[~nan])
+    # query_radius through the tier (Euclidean; Cosine for r < 1) against the exact scan, at a stored distance's value
+    rr = ed[0][np.isfinite(ed[0])]
+    if len(rr) and rr[-1] > 0 and (not cosine or rr[-1] < 1):
+        r = float(rr[-1])
+        sub = np.ascontiguousarray(qs[:200])
+        t.set_engine("exact")
+        xo, xi = t.query_radius_batch(sub, r)
+        t.set_engine("bf16")
+        go, gi = t.query_radius_batch(sub, r)
+        ok = ok and np.array_equal(go, xo) and np.array_equal(gi, xi)
     if not cosine:  # the oracle's brute force on a few queries
         sel = rng.choice(nq, 4, replace=False)
         bi, bd = oracle.brute_knn(pts, qs[sel], k)
