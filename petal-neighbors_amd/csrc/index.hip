@@ -2670,7 +2670,7 @@ static int radius_bf16_enqueue(const pn_index *ix, Workspace &ws, int level, con
     } else
         HIPCHK(launch_bf16_pack_queries(Qp, ix->d_mu, nq, nq_pad, (int)ix->dim, ix->ld, ws.w_bq.p, (double *)ws.w_qn.p,
                                         (uint32_t *)ws.w_qbad.p, ix->bf16_ci, ix->bf16_bmax, ix->bf16_dmax, s));
-    PNCHK(ws.w_gsel.ensure(nq * sizeof(uint32_t)));
+    PNCHK(ws.w_gsel.ensure(nq_pad * sizeof(uint32_t)));
     HIPCHK(launch_compact_flags((const uint32_t *)ws.w_qbad.p, (int)nq, (uint32_t *)ws.w_gsel.p, d_misc + 1, s));
     HIPCHK(launch_bf16_radius_tau((const double *)ws.w_qn.p, nq_pad, t, (uint32_t *)ws.w_seed.p, s));
     CandBuf cb{ws.w_idx.p, (uint32_t *)ws.w_idx.p + 1, (uint32_t *)ws.w_cnt.p, ws.w_tau.p, nq_pad, nseg, cap, 2};

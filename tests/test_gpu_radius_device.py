@@ -73,8 +73,9 @@ def test_radius_device_dense_neighbourhoods_take_the_listed_exact_pass(pn, oracl
 
 
 def test_radius_device_cosine_index_and_async(pn, oracle_mod):
-    """a Cosine index (exact two-pass scan for every query, device-driven) and the call's asynchrony: it returns while
-    work queued in front of it on its stream is still running"""
+    """a Cosine index (round 4: the bf16 tier over the normalised rows + Cosine::distance check for r < 1; the exact
+    two-pass scan, device-driven, with the engine set to exact) and the call's asynchrony: it returns while work queued in
+    front of it on its stream is still running"""
     import torch
     pts = (uniform((20000, 24), 6201) - np.float32(0.3)).astype(np.float32)
     qs = (uniform((100, 24), 6202) - np.float32(0.3)).astype(np.float32)
