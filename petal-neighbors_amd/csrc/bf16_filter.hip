@@ -3390,6 +3390,7 @@ constexpr bool kBf8Enabled = true;
 #define PN_BF8_MAXRUN 450
 #endif
 constexpr uint32_t kBf8MaxRun = PN_BF8_MAXRUN;  // runs shorter than this many tiles take the 8-wave main-pass kernel
+constexpr size_t kBf8MaxImage = (size_t)768 << 20;  // ... on corpora whose tile image is at most this large
 template <int KS, int M, bool RAD, bool CI>
 static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B, uint32_t q_tiles, uint32_t kp,
                                 const CandBuf &cb, int n_wg, uint32_t split, uint32_t spp, uint32_t scout_max,
@@ -3430,7 +3431,13 @@ static hipError_t launch_bf16_t(const void *img, uint32_t n_tiles, const void *B
         const uint32_t run_tiles = aligned ? n_tiles / ((uint32_t)n_wg / q_tiles) : 0u;
         // (second box: a 250 k-row shard, 326-tile runs, 2.5 % faster; a 500 k-row shard, 651 tiles, 3 % slower; 128-slot
         // buffers -- k = 100, survivors frequent -- 2 % faster at 1M x 128 and 10 % at 1M x 64 whatever the run length)
-        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && (M >= 2 || run_tiles < kBf8MaxRun));
+        // (end of round 4, profiles/r04_waves_ab_long_runs.log: on corpora whose image is far beyond the 256 MB Infinity
+        // Cache the 4-wave kernel wins at every buffer size -- 10M x 128: k = 100 193 vs 205 ms, k = 10 with 128-slot
+        // buffers 181 vs 196 ms; 12.5M x 96: 1.89 vs 2.01 s -- while at 1M rows the 8-wave kernel holds its 0-9 %: the
+        // automatic choice takes it only where the image is at most kBf8MaxImage bytes)
+        const size_t image_bytes = (size_t)n_tiles * kBP * (2 * KS + 1) * 16;
+        const bool want8 = cb.bf16_waves == 8 || (cb.bf16_waves == 0 && image_bytes <= kBf8MaxImage &&
+                                                  (M >= 2 || run_tiles < kBf8MaxRun));
         if (want8 && aligned && !scout_out && (tau_init || bsh.seed_lists) && kBf8Enabled) {
             if (use_sh && (!tau_init || shp->n_refresh < 1 || M > 2)) return hipErrorInvalidValue;
             BfShared a = bsh;

@@ -1251,7 +1251,7 @@ struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
     size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0;
     double model_dz = 0.0, model_rank = 0.0;
-    bool unaligned = false;
+    bool unaligned = false, model_shared_only = false;
     bool debug = false;
 };
 static const PlanKnobs &plan_knobs() {
@@ -1272,6 +1272,10 @@ static const PlanKnobs &plan_knobs() {
         v.model_dz = num("PN_EXP_MODEL_DZ", -2.0, 2.0);
         v.model_rank = num("PN_EXP_MODEL_RANK", 1.0, 1024.0);
         v.unaligned = getenv("PN_EXP_UNALIGNED") != nullptr;
+        {
+            const char *e = getenv("PN_EXP_MODEL_ALL_PLANS");
+            v.model_shared_only = e && e[0] == '0';
+        }
         v.debug = getenv("PN_DEBUG_PLAN") != nullptr;
         return v;
     }();
@@ -1742,7 +1746,9 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     // exp(4 sigma) for what the model gets wrong per query (sigma measured at build), times 1.5 per sticky widening
     // step.  Unlike the scout's seed (rank ~7.5 R: its sample holds Poisson(1.2) of the relevant rows) the model has no
     // sampling noise, so it starts every segment near the threshold it would end with: C2 kernel 2.32 -> 2.13 ms.
-    plan_seed_model(ix, p, R, kout, p.shared_scout || (plan_knobs().unaligned && p.ok && level == 0 && ix->filter_slots == 0));
+    // (plans WITHOUT a shared scout too -- one workgroup per query tile, grids in rounds: there the model replaces the
+    // scout pass every run would make over its own first tiles; PN_EXP_MODEL_ALL_PLANS=0 restricts it to shared-scout plans)
+    plan_seed_model(ix, p, R, kout, p.shared_scout || (!plan_knobs().model_shared_only && p.ok && level == 0 && ix->filter_slots == 0));
     p.n_refresh = 0;
     p.sh_rank = 0;
     // (with thresholds from the seed model the segments start where sharing would only bring them later: measured on

@@ -13,7 +13,7 @@ for c in $CFGS; do
         w8) W=8;;
         *) export PN_LIBRARY_PATH=$GRAFT_REPO_ROOT/petal-neighbors_amd/libpetal_mi355x_diag_$v.so;;
       esac
-      timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --config $c --waves $W > gpurun_out/abw_$v.json 2> gpurun_out/abw_$v.err || { echo "$c $v failed"; tail -3 gpurun_out/abw_$v.err; continue; }
+      timeout -k 10 300 python bench.py --no-cpu-baseline --steps ${PN_AB_STEPS:-20} --warmup ${PN_AB_WARMUP:-5} --config $c --waves $W > gpurun_out/abw_$v.json 2> gpurun_out/abw_$v.err || { echo "$c $v failed"; tail -3 gpurun_out/abw_$v.err; continue; }
       python3 -c "
 import json
 d=json.loads([l for l in open('gpurun_out/abw_$v.json') if l.startswith('{')][-1]); r=d['roofline']
