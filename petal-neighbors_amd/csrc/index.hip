@@ -10,9 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/petal_mi355x.h"
@@ -1314,16 +1316,27 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     const size_t r_tiles = wide ? (ix->n + 255) / 256 : (ix->n + 63) / 64;
     const size_t per = 2 * (size_t)bf16_scout_list();
     const size_t ld = ix->ld, cells = NQ * (size_t)NSEG, words = cells * per;
-    DevTmp mom, qrows, bq, qn, qbad, lists, keys, cnt, tau;
-    HIPCHK(mom.alloc(4 * (size_t)dim * sizeof(double)));
-    HIPCHK(qrows.alloc(NQ * ld * sizeof(T)));
-    HIPCHK(bq.alloc(bf16_query_bytes(NQ, dim, ix->bf16_ci)));
-    HIPCHK(qn.alloc(NQ * sizeof(double)));
-    HIPCHK(qbad.alloc(NQ * sizeof(uint32_t)));
-    HIPCHK(lists.alloc(words * sizeof(float)));
-    HIPCHK(keys.alloc(cells * 64 * 8));
-    HIPCHK(cnt.alloc(cells * sizeof(uint32_t)));
-    HIPCHK(tau.alloc(cells * sizeof(uint32_t)));
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // one allocation for all device temporaries (every hipFree waits for the device: nine of them cost the build ~10 ms)
+    struct Part { void *p = nullptr; } mom, qrows, bq, qn, qbad, lists, keys, cnt, tau;
+    DevTmp blk;
+    {
+        const size_t sizes[9] = {4 * (size_t)dim * sizeof(double), NQ * ld * sizeof(T), bf16_query_bytes(NQ, dim, ix->bf16_ci),
+                                 NQ * sizeof(double), NQ * sizeof(uint32_t), words * sizeof(float), cells * 64 * 8,
+                                 cells * sizeof(uint32_t), cells * sizeof(uint32_t)};
+        Part *parts[9] = {&mom, &qrows, &bq, &qn, &qbad, &lists, &keys, &cnt, &tau};
+        size_t total = 0;
+        for (size_t sz : sizes) total += round_up(sz, (size_t)256);
+        HIPCHK(blk.alloc(total));
+        size_t off = 0;
+        for (int i = 0; i < 9; ++i) {
+            parts[i]->p = (char *)blk.p + off;
+            off += round_up(sizes[i], (size_t)256);
+        }
+    }
     HIPCHK(hipMemsetAsync(mom.p, 0, 4 * (size_t)dim * sizeof(double), s));
     HIPCHK(launch_bf16_column_moments<T>(rows, ix->d_mu, ix->n, dim, ld, (double *)mom.p, s));
     const size_t stride = ix->n / NQ;
@@ -1356,6 +1369,7 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(h_mu.data(), ix->d_mu, h_mu.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_lists.data(), lists.p, words * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const double t_dev = ms_since(t_begin);
     const double inv_n = 1.0 / (double)ix->n;
     std::vector<float> h_model(3 * ld, 0.0f);
     double c0 = 0.0, v0 = 0.0;
@@ -1369,14 +1383,16 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
         v0 += m4 - m2 * m2;
     }
     if (!(c0 > 0.0) || !(v0 > 0.0) || !std::isfinite(c0) || !std::isfinite(v0)) return PN_OK;
-    // per calibration query: its model mean / deviation (the pack kernel's arithmetic: f64 over the f32 model words) and
-    // its smallest bounds in ascending order, its own row (the smallest of all) dropped
-    constexpr size_t TOP = 1500;
+    // per calibration query: its model mean / deviation (the pack kernel's arithmetic: f64 over the f32 model words), the
+    // bounds at the grid's ranks (selection, no sort: nth_element from the largest rank down, each on the prefix the one
+    // before left; the query's own row -- the smallest of all -- shifts every rank by one) and, once z at rank 64 is
+    // known, how many of its bounds a threshold aimed there really has below it (a count)
+    const size_t top_rank = (size_t)16 << (kSeedModelGrid - 1);
     std::vector<double> qmean(NQ), qsd(NQ, 0.0);
-    std::vector<std::vector<float>> top(NQ);
-    std::vector<float> all((size_t)NSEG * per);
+    std::vector<float> gridv(NQ * (size_t)kSeedModelGrid), all((size_t)NQ * NSEG * per);
     size_t used = 0;
-    for (size_t q = 0; q < NQ; ++q) {
+    if ((size_t)NSEG * per <= top_rank + 1) return PN_OK;
+    auto one_query = [&](size_t q) {
         double mean = 0.0, var = 0.0;
         for (int k = 0; k < dim; ++k) {
             const double c = (double)h_q[q * ld + k] - (double)h_mu[k];
@@ -1384,23 +1400,47 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
             var += c * (c * (double)h_model[ld + k] - (double)h_model[2 * ld + k]);
         }
         var += v0;
-        if (!(var > 0.0) || !std::isfinite(var) || !std::isfinite(mean)) continue;
+        if (!(var > 0.0) || !std::isfinite(var) || !std::isfinite(mean)) return;
+        float *a = &all[q * (size_t)NSEG * per];
         for (size_t seg = 0; seg < (size_t)NSEG; ++seg)
-            std::memcpy(&all[seg * per], &h_lists[(seg * NQ + q) * per], per * sizeof(float));
-        const size_t keep = TOP + 1 < all.size() ? TOP + 1 : all.size();
-        std::partial_sort(all.begin(), all.begin() + (ptrdiff_t)keep, all.end());
-        if (!std::isfinite(all[keep - 1])) continue;  // (fewer rows than that: n >= 100000 rules it out)
-        top[q].assign(all.begin() + 1, all.begin() + (ptrdiff_t)keep);
+            std::memcpy(a + seg * per, &h_lists[(seg * NQ + q) * per], per * sizeof(float));
+        size_t hi = (size_t)NSEG * per;
+        bool ok = true;
+        for (int j = kSeedModelGrid - 1; j >= 0; --j) {
+            const size_t rho = (size_t)16 << j;  // rank rho without the query's own row = element rho (0-based) with it
+            std::nth_element(a, a + (ptrdiff_t)rho, a + (ptrdiff_t)hi);
+            gridv[q * kSeedModelGrid + (size_t)j] = a[rho];
+            ok = ok && std::isfinite(a[rho]);
+            hi = rho;
+        }
+        if (!ok) return;  // (fewer rows than that: n >= 100000 rules it out)
         qmean[q] = c0 - 2.0 * mean;
-        qsd[q] = std::sqrt(var);
-        ++used;
+        qsd[q] = std::sqrt(var);  // (> 0 marks the query as used)
+    };
+    {   // the selections are 5-7 ms of host time on one thread: eight threads take a query each in turn
+        constexpr size_t NT = 8;
+        std::vector<std::thread> pool;
+        bool threaded = true;
+        try {
+            for (size_t t = 0; t < NT; ++t)
+                pool.emplace_back([&, t] {
+                    for (size_t q = t; q < NQ; q += NT) one_query(q);
+                });
+        } catch (...) {  // no threads to be had: whatever was not started runs here
+            threaded = false;
+        }
+        const size_t started = pool.size();
+        for (std::thread &th : pool) th.join();
+        if (!threaded)
+            for (size_t t = started; t < NT; ++t)
+                for (size_t q = t; q < NQ; q += NT) one_query(q);
     }
+    for (size_t q = 0; q < NQ; ++q) used += qsd[q] > 0.0 ? 1u : 0u;
     if (used < NQ * 3 / 4) return PN_OK;
     for (int j = 0; j < kSeedModelGrid; ++j) {
-        const size_t rho = (size_t)16 << j;
         double zs = 0.0;
         for (size_t q = 0; q < NQ; ++q)
-            if (qsd[q] > 0.0) zs += (qmean[q] - (double)top[q][rho - 1]) / qsd[q];
+            if (qsd[q] > 0.0) zs += (qmean[q] - (double)gridv[q * kSeedModelGrid + (size_t)j]) / qsd[q];
         ix->sm_zgrid[j] = zs / (double)used;
     }
     // what the model gets wrong: thresholds aimed at rank 64 -- the rank each one really has among its query's bounds
@@ -1409,7 +1449,10 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     for (size_t q = 0; q < NQ; ++q) {
         if (!(qsd[q] > 0.0)) continue;
         const float S = (float)(qmean[q] - z64 * qsd[q]);
-        const size_t cnt_below = (size_t)(std::lower_bound(top[q].begin(), top[q].end(), S) - top[q].begin());
+        const float *a = &all[q * (size_t)NSEG * per];
+        size_t cnt_below = 0;  // (everything below a grid value sits in front of it after the selections: the prefix up to
+        for (size_t e = 0; e <= top_rank; ++e) cnt_below += a[e] < S ? 1u : 0u;  // the top rank holds every candidate)
+        if (cnt_below > 0) cnt_below -= 1;  // the query's own row
         const double l = std::log(((double)cnt_below + 0.5) / 64.0);
         ls += l;
         lss += l * l;
@@ -1420,6 +1463,8 @@ static int seed_model_build(pn_index *ix, const T *rows, hipStream_t s) {
     ix->sm_sigma = std::sqrt(lv > 0.0 ? lv : 0.0);
     bool mono = true;  // (z must fall as the rank grows)
     for (int j = 1; j < kSeedModelGrid; ++j) mono = mono && ix->sm_zgrid[j] < ix->sm_zgrid[j - 1];
+    if (plan_knobs().debug)
+        std::fprintf(stderr, "[pn seed model] build: device part %.2f ms, host part %.2f ms\n", t_dev, ms_since(t_begin) - t_dev);
     if (plan_knobs().debug)
         std::fprintf(stderr, "[pn seed model] n %zu dim %d: z at ranks 16..1024 = %.3f %.3f %.3f %.3f %.3f %.3f %.3f, log-rank "
                              "error at rank 64: mean %.3f sigma %.3f; c0 %.6g v0 %.6g\n",
