@@ -408,6 +408,14 @@ int pn_bf16_bounds_f32(const pn_index *index, const float *queries, size_t nq, s
  * in f64) and refuses the tier (bf16_eligible = 0, pn_last_error says why) when the error exceeds 2 % of the allowance.
  * This entry runs the check (again) and returns the measured fraction of the allowance in *ratio_out. */
 int pn_bf16_selftest(int device, float *ratio_out);
+/* ---- diagnostic: the handle's seed-model feedback (round 4).  Every finished bf16-tier call tells the
+ * handle whether its starting thresholds -- from the index's seed model or from a scout launch -- left queries unproven;
+ * the handle then aims higher, goes back to the scout, or (after 64 scouted calls, at most three times) gives the model
+ * another try.  This entry feeds one such observation (model_seed: the call was seeded by the model; `unproven` of `nq`
+ * queries went to the next tier) into the handle exactly as a finished call would and returns the state in out[4] =
+ * { off, widen steps, scouted calls since off, retries used }: tests drive the state machine without having to
+ * construct corpora and batches that defeat the model. */
+int pn_debug_seed_model_feedback(pn_index *index, int model_seed, uint64_t unproven, uint64_t nq, int32_t *out4);
 
 /* ---- synthetic data (bench / tests): uniform [0,1) with exactly 24 random
  * bits, x[i] = (mix32(seed, first_counter + i) >> 8) * 2^-24, generated in

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pn_fill_uniform_device_f32": (_i, [_vp, _u64, _u64, _u64, _i, _vp]),
     "pn_bf16_bounds_f32": (_i, [_vp, _vp, _sz, _sz, _ssz, _sz, _vp, _vp, _vp]),
     "pn_bf16_selftest": (_i, [_i, _vp]),
+    "pn_debug_seed_model_feedback": (_i, [_vp, _i, _u64, _u64, _vp]),
     "pn_sharded_query_radius_device_f32": (_i, [_vp, _vp, _sz, _sz, _sz, C.c_float, _vp, _vp, _sz, _vp, _vp]),
     "pn_sharded_query_radius_device_f64": (_i, [_vp, _vp, _sz, _sz, _sz, C.c_double, _vp, _vp, _sz, _vp, _vp]),
     "pn_tree_num_nodes": (_i, [_vp, _u64p]),

@@ -194,6 +194,7 @@ struct CallRec {
 };
 constexpr int kCallRecs = 16;
 
+constexpr int kSeedModelRetry = 64, kSeedModelMaxRetries = 3;  // (see rec_resolve)
 constexpr int kSeedModelGrid = 7;  // seed model: z calibrated at the corpus ranks 16, 32, ..., 1024
 struct pn_index {
     int device = 0;
@@ -240,7 +241,9 @@ struct pn_index {
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
         int seed_model_widen = 0;     // calls seeded by the model left a few queries unproven: aim 1.5^this higher (sticky)
-        bool seed_model_off = false;  // a call seeded by the model left too many queries unproven: back to the scout (sticky)
+        bool seed_model_off = false;  // a call seeded by the model left too many queries unproven: back to the scout
+        int seed_model_off_calls = 0; // scouted calls since then: after kSeedModelRetry of them the model gets another try,
+        int seed_model_retries = 0;   // aiming 1.5x higher -- kSeedModelMaxRetries times, then it stays off
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
         // the reference's ball tree, built on first use of the introspection API (tree.cpp): published once, built under
         // tree_mu -- never under `mu`, which every query takes (an O(n d log n) host build must not block them)
@@ -790,6 +793,34 @@ struct WsLease {  // releases on every return path
 };
 
 // folds a finished record into the host-side statistics and the tier plan (caller holds sh.mu)
+// What a finished bf16-tier call teaches the handle about its seed model (under sh.mu; true: the call was the model's
+// business, the plan's level is left alone).  A call seeded by the model that leaves more than one query in 128 unproven:
+// the model does not fit these queries -- back to the scout; more than one in 1024: aim 1.5x higher, and off after four
+// such steps.  One odd batch must not cost the handle its model for good: after kSeedModelRetry scouted calls the model is
+// tried again, aiming 1.5x higher, at most kSeedModelMaxRetries times.
+static bool seed_model_feedback(pn_index::Shared &sh, bool model_seed, size_t nf, size_t nq) {
+    if (model_seed && nf * 128 > nq && nq >= 64) {
+        sh.seed_model_off = true;
+        sh.seed_model_off_calls = 0;
+        return true;
+    }
+    if (model_seed && nf * 1024 > nq && nq >= 256) {
+        if (++sh.seed_model_widen > 4) {
+            sh.seed_model_off = true;
+            sh.seed_model_off_calls = 0;
+        }
+        return true;
+    }
+    if (!model_seed && sh.seed_model_off && sh.seed_model_retries < kSeedModelMaxRetries &&
+        ++sh.seed_model_off_calls >= kSeedModelRetry) {
+        sh.seed_model_off = false;
+        sh.seed_model_off_calls = 0;
+        sh.seed_model_retries += 1;
+        if (sh.seed_model_widen < 4) sh.seed_model_widen += 1;
+        // (not the model's business otherwise: a scouted call that defeats the plan still raises the level below)
+    }
+    return false;
+}
 static void rec_resolve(const pn_index *ix, CallRec &r) {
     pn_index::Shared &sh = ix->sh;
     if (r.prof) {
@@ -826,11 +857,8 @@ static void rec_resolve(const pn_index *ix, CallRec &r) {
 #if !defined(PN_DIAG_BF_NOSLOW) && !defined(PN_DIAG_BF_NOSTORE) && !defined(PN_DIAG_BF_NOBARRIER) && !defined(PN_DIAG_BF_NOWAIT) && !defined(PN_DIAG_BF_NOAPPEND)  // timing-only builds flag queries by design
         // (a call seeded by the index's model instead of a scout launch: more than one query in 128 unproven means the
         // model does not fit these queries -- back to the scout, for good; the plan itself is not to blame)
-        if (r.model_seed && nf * 128 > r.nq && r.nq >= 64) sh.seed_model_off = true;
-        else if (r.model_seed && nf * 1024 > r.nq && r.nq >= 256) {
-            if (++sh.seed_model_widen > 4) sh.seed_model_off = true;
-        }
-        else if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
+        if (seed_model_feedback(sh, r.model_seed, nf, r.nq)) {
+        } else if (nf * 16 > r.nq && r.nq >= 64 && ix->filter_slots == 0 && sh.bf16_level < 2) sh.bf16_level += 1;
 #else
         (void)nf;
 #endif
@@ -2360,6 +2388,18 @@ extern "C" int pn_query_nearest_f32(const pn_index *ix, const float *q, size_t n
 extern "C" int pn_query_nearest_f64(const pn_index *ix, const double *q, size_t nq, size_t q_cols, ptrdiff_t q_stride,
                                     uint64_t *idx_out, double *dist_out) {
     return query_host_impl<double>(ix, q, nq, q_cols, q_stride, 1, idx_out, dist_out);
+}
+
+// diagnostic: one observation into the handle's seed-model feedback (see the header)
+extern "C" int pn_debug_seed_model_feedback(pn_index *ix, int model_seed, uint64_t unproven, uint64_t nq, int32_t *out4) {
+    if (!ix || !out4) return fail(PN_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(ix->sh.mu);
+    (void)seed_model_feedback(ix->sh, model_seed != 0, (size_t)unproven, (size_t)nq);
+    out4[0] = ix->sh.seed_model_off ? 1 : 0;
+    out4[1] = ix->sh.seed_model_widen;
+    out4[2] = ix->sh.seed_model_off_calls;
+    out4[3] = ix->sh.seed_model_retries;
+    return PN_OK;
 }
 
 // diagnostic: the bf16 filter's lower bounds themselves (see the header)

@@ -178,3 +178,47 @@ def test_model_on_wide_rows(pn):
     assert _same(on, want) and _same(off, want)
     assert st_on["fallback_queries"] <= nq // 64, st_on
     tree.close()
+
+
+def test_feedback_state_machine(pn):
+    """what finished calls teach a handle about its model (pn_debug_seed_model_feedback feeds observations exactly as a
+    finished call does): a few unproven queries -> aim higher; many -> back to the scout; 64 scouted calls later the
+    model gets another try, aiming higher, three times at most"""
+    import ctypes as C
+    from petal_neighbors_amd import _lib
+    pts = uniform((120_000, 32), 4500, np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    assert tree.seed_model
+    out = (C.c_int32 * 4)()
+
+    def feed(model, unproven, nq=10_000):
+        assert _lib.lib().pn_debug_seed_model_feedback(tree._h, int(model), unproven, nq, out) == 0
+        return tuple(out)
+
+    assert feed(True, 0) == (0, 0, 0, 0)
+    assert feed(True, 9) == (0, 0, 0, 0)            # 9 of 10^4: below one in 1024
+    assert feed(True, 12) == (0, 1, 0, 0)           # a few: aim 1.5x higher
+    assert feed(True, 200) == (1, 1, 0, 0)          # more than one in 128: back to the scout
+    for i in range(63):
+        assert feed(False, 0) == (1, 1, i + 1, 0)   # scouted calls are counted ...
+    assert feed(False, 0) == (0, 2, 0, 1)           # ... and the 64th gives the model another try, aiming higher
+    for retry in (2, 3):
+        assert feed(True, 500)[0] == 1
+        for _ in range(64):
+            st = feed(False, 0)
+        assert st[0] == 0 and st[3] == retry
+    assert feed(True, 500)[0] == 1                  # the third retry failed as well:
+    for _ in range(200):
+        st = feed(False, 0)
+    assert st[0] == 1 and st[3] == 3                # it stays off
+    # widening alone also ends in the scout: four steps, the fifth switches off
+    t2 = pn.BallTree.euclidean(pts)
+    seen = [_lib.lib().pn_debug_seed_model_feedback(t2._h, 1, 12, 10_000, out) or tuple(out) for _ in range(5)]
+    assert [s[1] for s in seen] == [1, 2, 3, 4, 5] and [s[0] for s in seen] == [0, 0, 0, 0, 1]
+    # and the answers of a handle in any of these states stay the exact engine's
+    qs = uniform((512, 32), 4501, np.float32)
+    for t in (tree, t2):
+        want = _exact(pn, t, qs, 10)
+        t.set_engine("bf16")
+        assert _same(t.query_batch(qs, 10), want)
+        t.close()
