@@ -53,7 +53,10 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 2
+/* 3 (round 4): + pn_query_radius_device_*, pn_sharded_query_radius_device_*, pn_bf16_selftest,
+ * pn_debug_seed_model_feedback, PN_OPT_BF16_WAVES, PN_OPT_SEED_MODEL, pn_info.seed_model (the former reserved word);
+ * PN_OPT_MFMA_STRUCTURE = 1 is now PN_ERR_INVALID.  Everything of version 2 is unchanged. */
+#define PN_ABI_VERSION 3
 
 /* ---- error codes.  EMPTY / NOT_CONTIGUOUS are ArrayError (src/lib.rs:9-16). */
 enum {

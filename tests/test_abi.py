@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol(pn):
     exported = set(re.findall(r" T (pn_[a-z0-9_]+)", out.stdout))
     missing = [s for s in declared if s not in exported]
     assert not missing, f"not exported: {missing}"
-    assert _lib.lib().pn_abi_version() == 2
+    assert _lib.lib().pn_abi_version() == 3
 
 
 def test_gfx950_code_object_is_embedded(pn):
