@@ -1279,7 +1279,7 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 // feed NaN or negative numbers into plan geometry.  0 = not set.
 struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
-    size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0;
+    size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0, min_per_tile = 0;
     double model_dz = 0.0, model_rank = 0.0;
     bool unaligned = false, model_shared_only = false;
     bool debug = false;
@@ -1299,6 +1299,7 @@ static const PlanKnobs &plan_knobs() {
         v.sh_min_run = (size_t)num("PN_EXP_SH_MIN_RUN", 1.0, 1.0e6);
         v.wide_per_tile = (size_t)num("PN_EXP_WIDE_PER_TILE", 1.0, 32.0);
         v.model_kmax = (size_t)num("PN_EXP_MODEL_KMAX", 1.0, 1024.0);
+        v.min_per_tile = (size_t)num("PN_EXP_MIN_PER_TILE", 1.0, 32.0);
         v.model_dz = num("PN_EXP_MODEL_DZ", -2.0, 2.0);
         v.model_rank = num("PN_EXP_MODEL_RANK", 1.0, 1024.0);
         v.unaligned = getenv("PN_EXP_UNALIGNED") != nullptr;
@@ -1658,6 +1659,13 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
     }
     size_t c = 1;
     while (c < c_max && eff_of(c) < best_eff - 0.05) ++c;
+    // (end of round 4: never ONE workgroup per query tile when two fill the slots as well -- a run over the whole corpus
+    // is the one shape where every relevant row of a query lands in one buffer (k' = R + 5 sqrt(R) + 3 and still a few
+    // unproven queries per 10^6, each an exact scan of the corpus) and where co-walking workgroups have the longest way
+    // to drift apart; a 12.5M x 96 shard of configs[4], 10^6 queries: 1 / 2 / 3 / 4 ranges 1931 / 1861 / 1855 / 1864 ms,
+    // profiles/r04_min_per_tile.log)
+    if (c == 1 && c_max >= 2 && eff_of(2) >= best_eff - 0.05) c = 2;
+    if (plan_knobs().min_per_tile > c && plan_knobs().min_per_tile <= c_max) c = plan_knobs().min_per_tile;  // experiments only
     return q_tiles * c;
 }
 static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int level) {
