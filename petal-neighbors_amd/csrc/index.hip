@@ -1665,6 +1665,10 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
     // to drift apart; a 12.5M x 96 shard of configs[4], 10^6 queries: 1 / 2 / 3 / 4 ranges 1931 / 1861 / 1855 / 1864 ms,
     // profiles/r04_min_per_tile.log)
     if (c == 1 && c_max >= 2 && eff_of(2) >= best_eff - 0.05) c = 2;
+    // (and runs beyond half a million tiles are cut once more: configs[4] whole, 10^8 x 96 -- 2 / 4 / 8 ranges 15.6 / 14.85 /
+    // 16.25 s per 10^6 queries; co-walking workgroups have 781 k tiles to drift apart in with two ranges, and the
+    // counters show it: 4.2 TB through the L2's memory side per chunk against 0.33 TB if they stayed together)
+    if (c < 4 && c_max >= 4 && r_tiles / c > 500000 && eff_of(4) >= best_eff - 0.05) c = 4;
     if (plan_knobs().min_per_tile > c && plan_knobs().min_per_tile <= c_max) c = plan_knobs().min_per_tile;  // experiments only
     return q_tiles * c;
 }
