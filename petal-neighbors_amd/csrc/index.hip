@@ -240,8 +240,10 @@ struct pn_index {
         unsigned next_rec = 0;
         uint64_t next_call = 1, stats_call = 0;
         int bf16_level = 0;  // 0 default plan, 1 conservative k', 2 tier off (raised when a call falls back too much)
-        int seed_model_widen = 0;     // calls seeded by the model left a few queries unproven: aim 1.5^this higher (sticky)
-        bool seed_model_off = false;  // a call seeded by the model left too many queries unproven: back to the scout
+        // (these two are read by the planner without sh.mu -- a plan may see either side of an update, both are valid --
+        // and written under it: atomics, so that the read is not a data race)
+        std::atomic<int> seed_model_widen{0};     // calls seeded by the model left a few queries unproven: aim 1.5^this higher (sticky)
+        std::atomic<bool> seed_model_off{false};  // a call seeded by the model left too many queries unproven: back to the scout
         int seed_model_off_calls = 0; // scouted calls since then: after kSeedModelRetry of them the model gets another try,
         int seed_model_retries = 0;   // aiming 1.5x higher -- kSeedModelMaxRetries times, then it stays off
         pn_stats stats{};    // host-side part: queries, radius_results, hot_*, last_call_ms
@@ -805,7 +807,7 @@ static bool seed_model_feedback(pn_index::Shared &sh, bool model_seed, size_t nf
         return true;
     }
     if (model_seed && nf * 1024 > nq && nq >= 256) {
-        if (++sh.seed_model_widen > 4) {
+        if (sh.seed_model_widen.fetch_add(1) + 1 > 4) {
             sh.seed_model_off = true;
             sh.seed_model_off_calls = 0;
         }
@@ -816,7 +818,7 @@ static bool seed_model_feedback(pn_index::Shared &sh, bool model_seed, size_t nf
         sh.seed_model_off = false;
         sh.seed_model_off_calls = 0;
         sh.seed_model_retries += 1;
-        if (sh.seed_model_widen < 4) sh.seed_model_widen += 1;
+        if (sh.seed_model_widen.load() < 4) sh.seed_model_widen.fetch_add(1);
         // (not the model's business otherwise: a scouted call that defeats the plan still raises the level below)
     }
     return false;
@@ -1530,11 +1532,11 @@ struct Bf16Plan {
 static void plan_seed_model(const pn_index *ix, Bf16Plan &p, double R, size_t kout, bool eligible) {
     p.model_seed = false;
     p.model_z = 0.0;
-    if (!eligible || !ix->sm_ok || ix->seed_model == 0 || ix->sh.seed_model_off ||
+    if (!eligible || !ix->sm_ok || ix->seed_model == 0 || ix->sh.seed_model_off.load(std::memory_order_relaxed) ||
         kout > (plan_knobs().model_kmax ? plan_knobs().model_kmax : (size_t)128) || ix->n < 100000)
         return;
     const double sig = ix->sm_sigma > 0.05 ? ix->sm_sigma : 0.05;
-    double rho_t = (R + 5.5 * std::sqrt(R)) * std::exp(4.0 * sig) * std::pow(1.5, (double)ix->sh.seed_model_widen);
+    double rho_t = (R + 5.5 * std::sqrt(R)) * std::exp(4.0 * sig) * std::pow(1.5, (double)ix->sh.seed_model_widen.load(std::memory_order_relaxed));
     if (plan_knobs().model_rank > 0.0) rho_t = plan_knobs().model_rank;  // experiments only
     if (rho_t < 16.0) rho_t = 16.0;
     const double top_rank = (double)(16u << (kSeedModelGrid - 1));
@@ -2407,8 +2409,8 @@ extern "C" int pn_debug_seed_model_feedback(pn_index *ix, int model_seed, uint64
     if (!ix || !out4) return fail(PN_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(ix->sh.mu);
     (void)seed_model_feedback(ix->sh, model_seed != 0, (size_t)unproven, (size_t)nq);
-    out4[0] = ix->sh.seed_model_off ? 1 : 0;
-    out4[1] = ix->sh.seed_model_widen;
+    out4[0] = ix->sh.seed_model_off.load() ? 1 : 0;
+    out4[1] = ix->sh.seed_model_widen.load();
     out4[2] = ix->sh.seed_model_off_calls;
     out4[3] = ix->sh.seed_model_retries;
     return PN_OK;
