@@ -1645,7 +1645,7 @@ static Bf16Plan bf16_plan_wide(const pn_index *ix, size_t nq_pad, size_t kout, i
 // workgroups (different query tiles, same row ranges) walk the same rows at the same time and share them in L2;
 // 2 n_cu persistent equal slices straddle query tiles and walk unrelated rows (configs[2], 10^7 x 128, 10^5
 // queries, k = 100: 291 -> 255 ms; one shard of configs[4], 1.25 10^7 x 96, 10^6 queries: 2.40 -> 2.28 s).
-static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, size_t n_wg) {
+static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, size_t n_wg, bool two_rounds_ok = false) {
     if (ix->opt_segments != 0 || n_wg != 2 * (size_t)ix->n_cu) return n_wg;
     const size_t slots = n_wg;
     auto eff_of = [&](size_t c) {
@@ -1671,6 +1671,15 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
     // 16.25 s per 10^6 queries; co-walking workgroups have 781 k tiles to drift apart in with two ranges, and the
     // counters show it: 4.2 TB through the L2's memory side per chunk against 0.33 TB if they stayed together)
     if (c < 4 && c_max >= 4 && r_tiles / c > 500000 && eff_of(4) >= best_eff - 0.05) c = 4;
+    // (and a grid that fills ONE round of slots poorly takes two rounds of shorter runs when those fill the slots at
+    // least 2.5 % better: C2, 40 query tiles on 512 slots -- 12 ranges per tile = 480 workgroups (93.75 %) against 25 =
+    // 1000 (97.7 % of two rounds): main launch 2.00-2.02 -> 1.95-1.96 ms; a 125 k- / 250 k-row shard of it -2 / -2.8 %,
+    // 1M x 96 -3.6 %, k = 1 -2.8 % (profiles/r04_two_rounds.log).  Small k only: at k = 100 the kernel gains 5 % and the
+    // re-rank of 25 cells per query gives it back.  With thresholds from the seed model a run costs little to start.)
+    if (two_rounds_ok && q_tiles * c <= slots) {
+        const size_t c2 = 2 * slots / q_tiles;
+        if (c2 > c && c2 <= c_max && r_tiles / c2 >= 64 && eff_of(c2) >= eff_of(c) + 0.025) c = c2;
+    }
     if (plan_knobs().min_per_tile > c && plan_knobs().min_per_tile <= c_max) c = plan_knobs().min_per_tile;  // experiments only
     return q_tiles * c;
 }
@@ -1694,7 +1703,8 @@ static Bf16Plan bf16_plan(const pn_index *ix, size_t nq_pad, size_t kout, int le
     if (ix->opt_segments > 0 && q_tiles * (size_t)ix->opt_segments < cap_wg) cap_wg = q_tiles * (size_t)ix->opt_segments;
     if (cap_wg < 1) cap_wg = 1;
     if (n_wg > cap_wg) n_wg = cap_wg;
-    if (q_tiles > 2 && !plan_knobs().unaligned) n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg);  // (many query tiles: a grid run in rounds)
+    if (q_tiles > 2 && !plan_knobs().unaligned)  // (many query tiles: a grid run in rounds)
+        n_wg = bf16_grid_wgs(ix, q_tiles, r_tiles, n_wg, kout <= 32 && level == 0 && ix->sm_ok && ix->seed_model != 0);
     // a whole number of workgroups per query tile: each workgroup's slice is then ONE run.  A slice that straddles
     // a query-tile boundary is two runs, each with its own operand load, scout pass and buffer warm-up, and those
     // workgroups set the kernel's time (C2: 512 workgroups = 12.8 per tile 4.34 ms, 480 = 12 per tile 3.62 ms)
