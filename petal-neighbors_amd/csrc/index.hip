@@ -1659,8 +1659,22 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
         c_max = c;
         if (eff_of(c) > best_eff) best_eff = eff_of(c);
     }
+    // (small k on a seed-model plan: runs are cheap to start, so the grid takes the fewest ranges within ONE percent of the
+    // best fill, not five, among those that leave runs of 64 tiles -- 10M x 128, 10^5 queries, k = 10: 5 -> 9 ranges per
+    // tile, 183.4 -> 174.2 ms; 1M x 96, 2 10^5 queries: 5 -> 13, 35.4 -> 32.6 ms; C2: 12 -> 25, below)
+    const double tol = two_rounds_ok ? 0.01 : 0.05;
+    if (two_rounds_ok) {
+        best_eff = eff_of(1);
+        size_t c_fine = 1;
+        for (size_t c = 2; c <= c_max; ++c) {
+            if (r_tiles / c < 64) break;
+            c_fine = c;
+            if (eff_of(c) > best_eff) best_eff = eff_of(c);
+        }
+        c_max = c_fine;
+    }
     size_t c = 1;
-    while (c < c_max && eff_of(c) < best_eff - 0.05) ++c;
+    while (c < c_max && eff_of(c) < best_eff - tol) ++c;
     // (end of round 4: never ONE workgroup per query tile when two fill the slots as well -- a run over the whole corpus
     // is the one shape where every relevant row of a query lands in one buffer (k' = R + 5 sqrt(R) + 3 and still a few
     // unproven queries per 10^6, each an exact scan of the corpus) and where co-walking workgroups have the longest way
