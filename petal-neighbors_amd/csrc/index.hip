@@ -1282,7 +1282,7 @@ static size_t mfma_slots(const pn_index *ix, size_t kout, size_t nq_pad) {
 struct PlanKnobs {
     double scout_lambda = 0.0, scout_cap = 0.0;
     size_t sh_min_run = 0, wide_per_tile = 0, model_kmax = 0, min_per_tile = 0;
-    double model_dz = 0.0, model_rank = 0.0;
+    double model_dz = 0.0, model_rank = 0.0, fill_tol = 0.0;
     bool unaligned = false, model_shared_only = false;
     bool debug = false;
 };
@@ -1304,6 +1304,7 @@ static const PlanKnobs &plan_knobs() {
         v.min_per_tile = (size_t)num("PN_EXP_MIN_PER_TILE", 1.0, 32.0);
         v.model_dz = num("PN_EXP_MODEL_DZ", -2.0, 2.0);
         v.model_rank = num("PN_EXP_MODEL_RANK", 1.0, 1024.0);
+        v.fill_tol = num("PN_EXP_FILL_TOL", 0.001, 0.5);
         v.unaligned = getenv("PN_EXP_UNALIGNED") != nullptr;
         {
             const char *e = getenv("PN_EXP_MODEL_ALL_PLANS");
@@ -1662,7 +1663,11 @@ static size_t bf16_grid_wgs(const pn_index *ix, size_t q_tiles, size_t r_tiles, 
     // (small k on a seed-model plan: runs are cheap to start, so the grid takes the fewest ranges within ONE percent of the
     // best fill, not five, among those that leave runs of 64 tiles -- 10M x 128, 10^5 queries, k = 10: 5 -> 9 ranges per
     // tile, 183.4 -> 174.2 ms; 1M x 96, 2 10^5 queries: 5 -> 13, 35.4 -> 32.6 ms; C2: 12 -> 25, below)
-    const double tol = two_rounds_ok ? 0.01 : 0.05;
+    // (not on corpora beyond 32M rows: configs[4] whole, 10^8 x 96 -- the 835-tile chunk with 11 ranges instead of 3 made the
+    // step 1.5 % SLOWER on the same device, as 8 ranges instead of 4 did for the other chunks)
+    if (r_tiles > 500000) two_rounds_ok = false;
+    double tol = two_rounds_ok ? 0.01 : 0.05;
+    if (plan_knobs().fill_tol > 0.0) tol = plan_knobs().fill_tol;  // experiments only
     if (two_rounds_ok) {
         best_eff = eff_of(1);
         size_t c_fine = 1;
