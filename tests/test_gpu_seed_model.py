@@ -222,3 +222,21 @@ def test_feedback_state_machine(pn):
         t.set_engine("bf16")
         assert _same(t.query_batch(qs, 10), want)
         t.close()
+
+
+def test_model_per_shard_of_a_sharded_handle(pn):
+    """three virtual shards of 110 k rows each build their own model; PN_OPT_SEED_MODEL is forwarded to every shard;
+    answers equal the unsharded index's with the option on and off"""
+    from petal_neighbors_amd.sharded import ShardedIndex
+    n, dim, nq = 330_000, 32, 1500
+    pts = uniform((n, dim), 4600, np.float32)
+    qs = uniform((nq, dim), 4601, np.float32)
+    tree = pn.BallTree.euclidean(pts)
+    want = _exact(pn, tree, qs, 10)
+    sh = ShardedIndex.from_host(pts, [0, 0, 0])
+    for v in (1, 0):
+        sh.set_option(PN_OPT_SEED_MODEL, v)
+        gi, gd = sh.query_batch(qs, 10)
+        assert np.array_equal(np.asarray(gi, dtype=np.uint64), want[0]) and np.asarray(gd).tobytes() == want[1].tobytes(), v
+    sh.close()
+    tree.close()
