@@ -3386,8 +3386,11 @@ constexpr bool kBf8Enabled = false;
 #else
 constexpr bool kBf8Enabled = true;
 #endif
+// (450 until the end of round 4; with thresholds from the seed model and 25 row ranges per query tile a 500 k-row shard
+// of C2 runs 312-tile runs and the 4-wave kernel is 3.5 % faster there, 156- and 78-tile runs are even / 1 % in favour
+// of 8 waves: profiles/r04_waves_ab_model.log)
 #ifndef PN_BF8_MAXRUN
-#define PN_BF8_MAXRUN 450
+#define PN_BF8_MAXRUN 200
 #endif
 constexpr uint32_t kBf8MaxRun = PN_BF8_MAXRUN;  // runs shorter than this many tiles take the 8-wave main-pass kernel
 constexpr size_t kBf8MaxImage = (size_t)768 << 20;  // ... on corpora whose tile image is at most this large
